@@ -1,0 +1,19 @@
+"""ray-tracing_amd — MI355X-native per-pixel path-tracing hot path (reference: stneng/Ray-Tracing).
+
+Layout:
+  csrc/   hand-written HIP kernels for gfx950 + the C-ABI of include/rt_hip.h  -> librt_hip.so
+  host/   C++ mirror of the reference's scene API, scenes.rs constructors, flattener -> librt_host.so
+  renderer.py  launcher: flatten -> upload -> render (spp-sharded) -> all-reduce -> resolve
+
+The directory name carries a hyphen, so import it with
+    importlib.import_module("ray-tracing_amd")      (or `import ray_tracing_amd`, the alias at the repo root)
+"""
+from ._ffi import RT_F32, RT_F64, RtError  # noqa: F401
+from ._build import build_all  # noqa: F401
+
+
+def __getattr__(name):  # renderer needs torch; keep `import` of the package itself light
+    if name in ("HostScene", "DeviceScene", "render", "resolve", "write_png", "init", "spp_shard", "SCENES", "DEFAULT_SEED", "EARTHMAP"):
+        from . import renderer
+        return getattr(renderer, name)
+    raise AttributeError(name)

@@ -1,0 +1,74 @@
+"""Compile the native pieces in-tree (no JIT cache): the HIP C-ABI library for gfx950 and the
+C++ host library.  Run here on CPU (hipcc cross-compiles); the built .so files travel to the GPU
+box with the tree."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB_HIP = os.path.join(PKG, "librt_hip.so")
+LIB_HOST = os.path.join(PKG, "librt_host.so")
+OBJ = os.path.join(PKG, "csrc", "_obj")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")]
+# (source, extra flags).  The f64 unit must round every operation separately (the reference's
+# Rust f64 code has no fused multiply-add), so contraction is off there and only there.
+UNITS = [
+    ("rt_kernels_f64.hip", ["-O3", "-ffp-contract=off"]),
+    ("rt_kernels_f32.hip", ["-O3", "-ffp-contract=fast"]),
+    ("rt_hip.hip", ["-O2"]),
+]
+HOST_SRC = ["scene_api.cpp", "scenes.cpp", "flatten.cpp", "capi.cpp"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-shared"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+
+
+def build_hip(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
+    headers.append(os.path.join(ROOT, "include", "rt_hip.h"))
+    objs = []
+    for src, flags in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + headers):
+            _run([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
+        objs.append(o)
+    if force or _newer(LIB_HIP, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_HIP] + objs)
+    return LIB_HIP
+
+
+def build_host(force=False):
+    srcs = [os.path.join(HOST, f) for f in HOST_SRC]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
+    deps += [os.path.join(ROOT, "include", "rt_hip.h"), os.path.join(ROOT, "include", "rt_host.h")]
+    if force or _newer(LIB_HOST, deps):
+        _run(["g++"] + HOST_FLAGS + ["-o", LIB_HOST] + srcs)
+    return LIB_HOST
+
+
+def build_all(force=False):
+    return build_hip(force), build_host(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

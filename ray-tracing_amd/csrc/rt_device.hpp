@@ -1,0 +1,611 @@
+// rt_device.hpp — device-side path tracing for gfx950, templated on the arithmetic type T
+// (double: restates the reference's f64 arithmetic operation-for-operation; float: throughput).
+//
+// The reference's recursive, dyn-dispatched ray_color (src/ray_tracing.rs:11-60) becomes an
+// iterative per-lane state machine; the Object/Material/Texture/PDF traits become switches over
+// tagged records.  Every routine cites the reference lines whose arithmetic (and evaluation
+// order, strict/inclusive comparisons, NaN behaviour) it keeps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// ------------------------------------------------------------------------------------------
+// device layouts (built by rt_scene_create from the f64 RtSceneDesc)
+// ------------------------------------------------------------------------------------------
+template <class T> struct DPrim { T d[10]; uint32_t kind, material; };
+template <class T> struct DMaterial { T albedo[3]; T fuzz, ref_idx; uint32_t kind, texture; };
+template <class T> struct DTexture { T color[3]; T scale; uint32_t kind, odd, even, table; };
+template <class T> struct DPerlin { T ranvec[256][3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; };
+struct DImage { const uint8_t* rgb; uint32_t width, height; };
+template <class T> struct DXform { T v[3]; uint32_t kind; };
+template <class T> struct DInstance { T density; uint32_t geom_kind, geom_index, xform_begin, xform_count, is_medium, phase_material; };
+// Threaded BVH: the reference's fixed left-then-right recursion (src/bvh.rs:114-129) needs no
+// stack when internal nodes AND leaves are laid out in pre-order and each internal node knows
+// where its subtree ends: box hit -> next entry, box miss -> skip.  prim >= 0 marks a leaf.
+template <class T> struct DBvhEntry { T mn[3], mx[3]; int32_t skip, prim; };
+template <class T> struct DCamera { T origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3]; T lens_radius, t1, t2; };
+
+template <class T> struct DScene {
+    const DPrim<T>* prims;
+    const DMaterial<T>* materials;
+    const DTexture<T>* textures;
+    const DPerlin<T>* perlins;
+    const DImage* images;
+    const DXform<T>* xforms;
+    const DInstance<T>* world;
+    const DInstance<T>* lights;
+    const DBvhEntry<T>* bvh;
+    const int32_t* bvh_root_entry;  // node index (RtBvh numbering) -> entry index, for instance roots
+    uint32_t n_world, n_lights;
+    T background[3];
+    DCamera<T> cam;
+};
+
+struct RenderArgs {
+    uint32_t width, height, spp_begin, spp_count;
+    int32_t max_depth;
+    uint32_t max_nan_retries;
+    uint64_t seed;
+};
+
+// ------------------------------------------------------------------------------------------
+// math helpers
+// ------------------------------------------------------------------------------------------
+template <class T> struct Lim;
+template <> struct Lim<double> { static __device__ constexpr double max() { return 1.7976931348623157e308; } };
+template <> struct Lim<float> { static __device__ constexpr float max() { return 3.402823466e+38f; } };
+
+__device__ inline double sqrt_r(double x) { return ::sqrt(x); }
+__device__ inline float sqrt_r(float x) { return ::sqrtf(x); }
+__device__ inline double rsin(double x) { return ::sin(x); }
+__device__ inline float rsin(float x) { return ::sinf(x); }
+__device__ inline double rcos(double x) { return ::cos(x); }
+__device__ inline float rcos(float x) { return ::cosf(x); }
+__device__ inline double ratan2(double y, double x) { return ::atan2(y, x); }
+__device__ inline float ratan2(float y, float x) { return ::atan2f(y, x); }
+__device__ inline double rasin(double x) { return ::asin(x); }
+__device__ inline float rasin(float x) { return ::asinf(x); }
+__device__ inline double rlog(double x) { return ::log(x); }
+__device__ inline float rlog(float x) { return ::logf(x); }
+__device__ inline double rfloor(double x) { return ::floor(x); }
+__device__ inline float rfloor(float x) { return ::floorf(x); }
+__device__ inline double rabs(double x) { return ::fabs(x); }
+__device__ inline float rabs(float x) { return ::fabsf(x); }
+__device__ inline double rmin(double a, double b) { return ::fmin(a, b); }  // IEEE minNum == Rust f64::min
+__device__ inline float rmin(float a, float b) { return ::fminf(a, b); }
+__device__ inline double rmax(double a, double b) { return ::fmax(a, b); }
+__device__ inline float rmax(float a, float b) { return ::fmaxf(a, b); }
+
+template <class T> struct V3 {
+    T x, y, z;
+    __device__ V3() {}
+    __device__ V3(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+    __device__ explicit V3(const T* p) : x(p[0]), y(p[1]), z(p[2]) {}
+};
+// src/vec3.rs:56-206 (operator order kept; `*` between vectors is the dot product there)
+template <class T> __device__ inline V3<T> operator+(V3<T> a, V3<T> b) { return V3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> __device__ inline V3<T> operator-(V3<T> a, V3<T> b) { return V3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> __device__ inline V3<T> operator-(V3<T> a) { return V3<T>(-a.x, -a.y, -a.z); }
+template <class T> __device__ inline V3<T> operator*(V3<T> a, T b) { return V3<T>(a.x * b, a.y * b, a.z * b); }
+template <class T> __device__ inline V3<T> operator/(V3<T> a, T b) { return V3<T>(a.x / b, a.y / b, a.z / b); }
+template <class T> __device__ inline T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> __device__ inline T sqlen(V3<T> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <class T> __device__ inline T length(V3<T> a) { return sqrt_r(a.x * a.x + a.y * a.y + a.z * a.z); }
+template <class T> __device__ inline V3<T> elemul(V3<T> a, V3<T> b) { return V3<T>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <class T> __device__ inline V3<T> cross(V3<T> a, V3<T> b) {
+    return V3<T>(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
+}
+// src/vec3.rs:30-36; a zero vector yields NaN (the reference panics) -> the sample is retried
+template <class T> __device__ inline V3<T> unit(V3<T> a) { T len = length(a); return V3<T>(a.x / len, a.y / len, a.z / len); }
+
+template <class T> struct Ray { V3<T> ori, dir; T time; };
+template <class T> __device__ inline V3<T> at(const Ray<T>& r, T t) { return r.ori + r.dir * t; }  // src/ray.rs:12-14
+
+template <class T> struct Consts;
+template <> struct Consts<double> { static __device__ constexpr double pi() { return 3.14159265358979323846; } };
+template <> struct Consts<float> { static __device__ constexpr float pi() { return 3.14159265358979323846f; } };
+
+// ------------------------------------------------------------------------------------------
+// RNG: xoshiro128++ keyed by (seed, pixel, sample) through splitmix64.  Same specification as the
+// oracle's rng.hpp (the reference's generators are entropy-seeded: only distributions matter).
+// ------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t s0, s1, s2, s3;
+    static __device__ inline uint64_t splitmix64(uint64_t& z) {
+        z += 0x9E3779B97F4A7C15ull;
+        uint64_t r = z;
+        r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull;
+        r = (r ^ (r >> 27)) * 0x94D049BB133111EBull;
+        return r ^ (r >> 31);
+    }
+    __device__ inline void init(uint64_t seed, uint32_t pixel, uint32_t sample) {
+        uint64_t key = ((uint64_t)pixel << 32) | sample;
+        uint64_t z = seed + key * 0x9E3779B97F4A7C15ull;
+        uint64_t a = splitmix64(z);
+        uint64_t b = splitmix64(z);
+        s0 = (uint32_t)a; s1 = (uint32_t)(a >> 32); s2 = (uint32_t)b; s3 = (uint32_t)(b >> 32);
+        if ((s0 | s1 | s2 | s3) == 0) s0 = 1;
+    }
+    static __device__ inline uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    __device__ inline uint32_t next_u32() {
+        uint32_t result = rotl(s0 + s3, 7) + s0;
+        uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+        s3 = rotl(s3, 11);
+        return result;
+    }
+    __device__ inline uint64_t next_u64() { uint64_t hi = next_u32(); uint64_t lo = next_u32(); return (hi << 32) | lo; }
+    // rand 0.7.3 gen::<f64>(): 53 high bits * 2^-53;  f32: 24 high bits * 2^-24
+    __device__ inline void gen(double& out) { out = (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    __device__ inline void gen(float& out) { out = (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+    template <class T> __device__ inline T gen() { T v; gen(v); return v; }
+    // rand 0.7.3 gen_range(lo,hi) for floats: fraction scaled into [lo,hi), redrawn if it rounds to hi
+    __device__ inline double gen_range(double lo, double hi) {
+        for (;;) {
+            double u = (double)(next_u64() >> 12) * (1.0 / 4503599627370496.0);
+            double v = lo + (hi - lo) * u;
+            if (v < hi) return v;
+        }
+    }
+    __device__ inline float gen_range(float lo, float hi) {
+        for (;;) {
+            float u = (float)(next_u32() >> 9) * (1.0f / 8388608.0f);
+            float v = lo + (hi - lo) * u;
+            if (v < hi) return v;
+        }
+    }
+    // rand 0.7.3 gen_range(0,n) for integers: widening multiply with rejection zone
+    __device__ inline uint32_t gen_index(uint32_t n) {
+        uint64_t m = (uint64_t)next_u32() * n;
+        uint32_t l = (uint32_t)m;
+        if (l < n) {
+            uint32_t thresh = (0u - n) % n;
+            while (l < thresh) { m = (uint64_t)next_u32() * n; l = (uint32_t)m; }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+// src/vec3.rs:208-216
+template <class T> __device__ inline V3<T> random_in_unit_sphere(Rng& rng) {
+    for (;;) {
+        T a = rng.gen<T>(); T b = rng.gen<T>(); T c = rng.gen<T>();
+        V3<T> t = V3<T>(a, b, c) * T(2) - V3<T>(T(1), T(1), T(1));
+        if (sqlen(t) <= T(1)) return t;
+    }
+}
+// src/vec3.rs:223-230
+template <class T> __device__ inline V3<T> random_in_unit_disk(Rng& rng) {
+    for (;;) {
+        T a = rng.gen<T>(); T b = rng.gen<T>();
+        V3<T> t = V3<T>(a, b, T(0)) * T(2) - V3<T>(T(1), T(1), T(0));
+        if (sqlen(t) <= T(1)) return t;
+    }
+}
+// src/vec3.rs:231-239
+template <class T> __device__ inline V3<T> random_cosine_direction(Rng& rng) {
+    T r1 = rng.gen<T>(); T r2 = rng.gen<T>();
+    T z = sqrt_r(T(1) - r2);
+    T phi = T(2) * Consts<T>::pi() * r1;
+    T x = rcos(phi) * sqrt_r(r2);
+    T y = rsin(phi) * sqrt_r(r2);
+    return V3<T>(x, y, z);
+}
+// src/vec3.rs:240-248
+template <class T> __device__ inline V3<T> random_to_sphere(T radius, T distance_squared, Rng& rng) {
+    T r1 = rng.gen<T>(); T r2 = rng.gen<T>();
+    T z = T(1) + r2 * (sqrt_r(T(1) - radius * radius / distance_squared) - T(1));
+    T phi = T(2) * Consts<T>::pi() * r1;
+    T x = rcos(phi) * sqrt_r(T(1) - z * z);
+    T y = rsin(phi) * sqrt_r(T(1) - z * z);
+    return V3<T>(x, y, z);
+}
+// src/vec3.rs:249-257
+template <class T> __device__ inline V3<T> reflect(V3<T> v, V3<T> n) { return v - n * T(2) * dot(v, n); }
+template <class T> __device__ inline V3<T> refract(V3<T> v, V3<T> n, T etai_over_etat) {
+    T cos_theta = rmin(dot(-v, n), T(1));
+    V3<T> r_out_perp = (v + n * cos_theta) * etai_over_etat;
+    V3<T> r_out_parallel = (-n) * sqrt_r(rabs(T(1) - sqlen(r_out_perp)));
+    return r_out_perp + r_out_parallel;
+}
+
+// src/pdf.rs:5-25
+template <class T> struct ONB { V3<T> u, v, w; };
+template <class T> __device__ inline ONB<T> onb_from_w(V3<T> w_in) {
+    ONB<T> o;
+    o.w = unit(w_in);
+    V3<T> a = rabs(o.w.x) > T(0.9) ? V3<T>(T(0), T(1), T(0)) : V3<T>(T(1), T(0), T(0));
+    o.v = unit(cross(o.w, a));
+    o.u = unit(cross(o.w, o.v));
+    return o;
+}
+template <class T> __device__ inline V3<T> onb_local(const ONB<T>& o, V3<T> a) { return o.u * a.x + o.v * a.y + o.w * a.z; }
+
+// ------------------------------------------------------------------------------------------
+// camera: src/camera.rs:57-65
+// ------------------------------------------------------------------------------------------
+template <class T> __device__ inline Ray<T> camera_ray(const DCamera<T>& c, T s, T t, V3<T> rd_unit, T time) {
+    V3<T> rd = rd_unit * c.lens_radius;
+    V3<T> offset = V3<T>(c.u) * rd.x + V3<T>(c.v) * rd.y;
+    Ray<T> r;
+    r.ori = V3<T>(c.origin) + offset;
+    r.dir = V3<T>(c.llc) + V3<T>(c.horizontal) * s + V3<T>(c.vertical) * t - V3<T>(c.origin) - offset;
+    r.time = time;
+    return r;
+}
+template <class T> __device__ inline Ray<T> get_ray(const DCamera<T>& c, T s, T t, Rng& rng) {
+    V3<T> rd = random_in_unit_disk<T>(rng);   // drawn even when lens_radius == 0
+    T time = rng.gen_range(c.t1, c.t2);
+    return camera_ray(c, s, t, rd, time);
+}
+
+// ------------------------------------------------------------------------------------------
+// primitive intersection (object-space ray).  Only t is produced during the closest-hit search;
+// p / normal / uv of the WINNING hit are computed afterwards by finish_hit with the reference's
+// formulas (the reference computes them for every candidate, including sphere uv before its range
+// check, src/objects.rs:95 — values that are discarded have no side effects).
+// ------------------------------------------------------------------------------------------
+// src/objects.rs:227-244, 281-298, 335-352.  axis 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x)
+template <class T>
+__device__ inline bool rect_hit(int axis, T a1, T a2, T b1, T b2, T k, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
+    T ok, dk, oa, da, ob, db;
+    if (axis == 0) { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+    else if (axis == 1) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
+    else { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+    T t = (k - ok) / dk;
+    if (t >= t_min && t <= t_max) {  // inclusive
+        T a = oa + t * da;
+        T b = ob + t * db;
+        if (a >= a1 && a <= a2 && b >= b1 && b <= b2) { t_out = t; return true; }
+    }
+    return false;
+}
+// src/objects.rs:87-119 / 160-193 (strict comparisons)
+template <class T>
+__device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
+    V3<T> oc = o - center;
+    T a = dot(d, d);
+    T half_b = dot(oc, d);
+    T c = dot(oc, oc) - radius * radius;
+    T discriminant = half_b * half_b - a * c;
+    if (discriminant > T(0)) {
+        T sq = sqrt_r(discriminant);
+        T ans = (-half_b - sq) / a;
+        if (ans > t_min && ans < t_max) { t_out = ans; return true; }
+        ans = (-half_b + sq) / a;
+        if (ans > t_min && ans < t_max) { t_out = ans; return true; }
+    }
+    return false;
+}
+// src/objects.rs:154-158
+template <class T> __device__ inline V3<T> moving_center(const DPrim<T>& p, T time) {
+    V3<T> c1(p.d), c2(p.d + 3);
+    return c1 + (c2 - c1) * ((time - p.d[6]) / (p.d[7] - p.d[6]));
+}
+// cuboid side i as a rect: src/objects.rs:399-452
+template <class T> __device__ inline void cuboid_side(const DPrim<T>& p, int i, int& axis, T& a1, T& a2, T& b1, T& b2, T& k, T& face) {
+    const T* mn = p.d; const T* mx = p.d + 3;
+    axis = i >> 1;
+    face = (i & 1) ? T(1) : T(-1);
+    if (axis == 0) { a1 = mn[0]; a2 = mx[0]; b1 = mn[1]; b2 = mx[1]; k = (i & 1) ? mx[2] : mn[2]; }
+    else if (axis == 1) { a1 = mn[0]; a2 = mx[0]; b1 = mn[2]; b2 = mx[2]; k = (i & 1) ? mx[1] : mn[1]; }
+    else { a1 = mn[1]; a2 = mx[1]; b1 = mn[2]; b2 = mx[2]; k = (i & 1) ? mx[0] : mn[0]; }
+}
+
+// Closest hit of ONE primitive in (t_min, t_max); side = cuboid face.
+template <class T>
+__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t_min, T t_max, T& t_out, int& side) {
+    side = 0;
+    switch (p.kind) {
+        case 0: return sphere_hit(V3<T>(p.d), p.d[3], o, d, t_min, t_max, t_out);
+        case 1: return sphere_hit(moving_center(p, time), p.d[8], o, d, t_min, t_max, t_out);
+        case 2: case 3: case 4:
+            return rect_hit<T>((int)p.kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+        default: {  // cuboid: six sides in tuple order, shrinking closest (src/objects.rs:458-485)
+            bool any = false;
+            T closest = t_max;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                int axis; T a1, a2, b1, b2, k, face;
+                cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
+                T t;
+                if (rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, t_min, closest, t)) { any = true; closest = t; side = i; }
+            }
+            t_out = closest;
+            return any;
+        }
+    }
+}
+
+// src/bvh.rs:26-58 — loose slab test, true divisions, minNum/maxNum
+template <class T> __device__ inline bool aabb_hit(const T* mn, const T* mx, V3<T> o, V3<T> d, T t_min, T t_max) {
+    {
+        T t1 = (mn[0] - o.x) / d.x, t2 = (mx[0] - o.x) / d.x;
+        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
+        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+    }
+    {
+        T t1 = (mn[1] - o.y) / d.y, t2 = (mx[1] - o.y) / d.y;
+        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
+        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+    }
+    {
+        T t1 = (mn[2] - o.z) / d.z, t2 = (mx[2] - o.z) / d.z;
+        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
+        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+    }
+    return true;
+}
+
+// Geometry of an instance: one primitive, or a threaded-BVH walk (src/bvh.rs:114-129: box test,
+// left subtree, then right subtree with t_max = best so far; strict/inclusive tie rules of the
+// leaf primitives decide equal-t replacement).
+template <class T>
+__device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, T time,
+                                T t_min, T t_max, T& t_out, int& prim_out, int& side_out, uint32_t& n_tests) {
+    if (geom_kind == 0) {
+        n_tests++;
+        prim_out = (int)geom_index;
+        return prim_hit(sc.prims[geom_index], o, d, time, t_min, t_max, t_out, side_out);
+    }
+    bool any = false;
+    T closest = t_max;
+    int i = sc.bvh_root_entry[geom_index];
+    const int end = sc.bvh[i].skip;
+    while (i != end) {
+        const DBvhEntry<T>& e = sc.bvh[i];
+        if (e.prim >= 0) {
+            T t; int side;
+            n_tests++;
+            if (prim_hit(sc.prims[e.prim], o, d, time, t_min, closest, t, side)) {
+                any = true; closest = t; prim_out = e.prim; side_out = side;
+            }
+            i = i + 1;
+        } else {
+            i = aabb_hit(e.mn, e.mx, o, d, t_min, closest) ? i + 1 : e.skip;
+        }
+    }
+    t_out = closest;
+    return any;
+}
+
+// src/transforms.rs:15-17, 90-103: world ray -> object ray through the instance's wrapper chain
+template <class T> __device__ inline void xform_ray(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
+    for (uint32_t j = 0; j < in.xform_count; j++) {
+        const DXform<T>& x = sc.xforms[in.xform_begin + j];
+        if (x.kind == 0) {
+            o = o - V3<T>(x.v);
+        } else {
+            T s = x.v[0], c = x.v[1];
+            o = V3<T>(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
+            d = V3<T>(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+        }
+    }
+}
+// transforms.rs:34-39,124-135: pdf_value / random forward only the origin through Translate and
+// origin + direction through RotateY
+template <class T> __device__ inline void xform_point_dir(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
+    xform_ray(sc, in, o, d);
+}
+// src/transforms.rs:18-21, 105-116: hit record back to world space (innermost wrapper first)
+template <class T> __device__ inline void xform_back(const DScene<T>& sc, const DInstance<T>& in, V3<T>& p, V3<T>& n) {
+    for (int j = (int)in.xform_count - 1; j >= 0; j--) {
+        const DXform<T>& x = sc.xforms[in.xform_begin + j];
+        if (x.kind == 0) {
+            p = p + V3<T>(x.v);
+        } else {
+            T s = x.v[0], c = x.v[1];
+            p = V3<T>(c * p.x + s * p.z, p.y, -s * p.x + c * p.z);
+            n = V3<T>(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
+        }
+    }
+}
+template <class T> __device__ inline V3<T> xform_dir_back(const DScene<T>& sc, const DInstance<T>& in, V3<T> v) {
+    for (int j = (int)in.xform_count - 1; j >= 0; j--) {
+        const DXform<T>& x = sc.xforms[in.xform_begin + j];
+        if (x.kind == 1) {
+            T s = x.v[0], c = x.v[1];
+            v = V3<T>(c * v.x + s * v.z, v.y, -s * v.x + c * v.z);
+        }
+    }
+    return v;
+}
+
+struct MediumXi {  // where ConstantMedium gets xi from: the path's generator, or a pinned probe value
+    Rng* rng;
+    double fixed;
+};
+template <class T> __device__ inline T medium_xi(MediumXi& m) { return m.rng ? m.rng->gen<T>() : (T)m.fixed; }
+
+template <class T> struct Hit {
+    T t;
+    int inst, prim, side;  // side 7 = ConstantMedium event
+};
+
+// src/objects.rs:38-48 (ObjectList::hit over the world) with Translate/RotateY wrappers and
+// ConstantMedium (src/objects.rs:529-556) folded in.
+template <class T>
+__device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min, T t_max, MediumXi& mxi, Hit<T>& hit,
+                                 uint32_t& n_tests) {
+    bool any = false;
+    T closest = t_max;
+    for (uint32_t i = 0; i < sc.n_world; i++) {
+        const DInstance<T>& in = sc.world[i];
+        V3<T> o = ray.ori, d = ray.dir;
+        xform_ray(sc, in, o, d);
+        T t; int prim = -1, side = 0;
+        if (!in.is_medium) {
+            if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, t_min, closest, t, prim, side, n_tests)) {
+                any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side;
+            }
+        } else {
+            T ta, tb;
+            if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, -Lim<T>::max(), Lim<T>::max(), ta, prim, side, n_tests)) {
+                int prim2, side2;
+                if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, ta + T(0.0001), Lim<T>::max(), tb, prim2, side2, n_tests)) {
+                    if (ta < t_min) ta = t_min;
+                    if (tb > closest) tb = closest;
+                    if (ta < tb) {
+                        T len = length(ray.dir);
+                        T distance_inside_boundary = (tb - ta) * len;
+                        T hit_distance = -(T(1) / in.density) * rlog(medium_xi<T>(mxi));
+                        if (hit_distance <= distance_inside_boundary) {
+                            t = ta + hit_distance / len;
+                            any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
+                            int first = (int)in.geom_index;  // boundary's first primitive in pre-order
+                            if (in.geom_kind != 0) {
+                                int e = sc.bvh_root_entry[in.geom_index];
+                                while (sc.bvh[e].prim < 0) e++;
+                                first = sc.bvh[e].prim;
+                            }
+                            hit.prim = first;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return any;
+}
+
+// src/objects.rs:208-215
+template <class T> __device__ inline void sphere_uv(V3<T> p, T& u, T& v) {
+    T phi = ratan2(p.z, p.x);
+    T theta = rasin(p.y);
+    u = T(1) - (phi + Consts<T>::pi()) / (T(2) * Consts<T>::pi());
+    v = (theta + Consts<T>::pi() / T(2)) / Consts<T>::pi();
+}
+
+template <class T> struct HitRecord { T t; V3<T> p, normal; T u, v; uint32_t material; };
+
+// Fill the HitRecord of the winning hit (reference formulas of each primitive's `hit`).
+template <class T>
+__device__ inline void finish_hit(const DScene<T>& sc, const Ray<T>& ray, const Hit<T>& h, bool need_uv, HitRecord<T>& rec) {
+    const DInstance<T>& in = sc.world[h.inst];
+    rec.t = h.t;
+    if (h.side == 7) {  // src/objects.rs:543-550
+        rec.p = at(ray, h.t);
+        rec.normal = V3<T>(T(1), T(0), T(0));
+        rec.u = T(0); rec.v = T(0);
+        rec.material = in.phase_material;
+        return;
+    }
+    Ray<T> r = ray;
+    xform_ray(sc, in, r.ori, r.dir);
+    const DPrim<T>& p = sc.prims[h.prim];
+    rec.material = p.material;
+    rec.u = T(0); rec.v = T(0);
+    if (p.kind <= 1) {
+        V3<T> center = p.kind == 0 ? V3<T>(p.d) : moving_center(p, ray.time);
+        T radius = p.kind == 0 ? p.d[3] : p.d[8];
+        rec.p = at(r, h.t);
+        rec.normal = (at(r, h.t) - center) / radius;
+        if (need_uv) {  // uv from the FIRST root even when the second was returned (objects.rs:94-95)
+            V3<T> oc = r.ori - center;
+            T a = dot(r.dir, r.dir);
+            T half_b = dot(oc, r.dir);
+            T c = dot(oc, oc) - radius * radius;
+            T discriminant = half_b * half_b - a * c;
+            T ans = (-half_b - sqrt_r(discriminant)) / a;
+            sphere_uv((at(r, ans) - center) / radius, rec.u, rec.v);
+        }
+    } else {
+        int axis; T a1, a2, b1, b2, k, face;
+        if (p.kind == 5) cuboid_side(p, h.side, axis, a1, a2, b1, b2, k, face);
+        else { axis = (int)p.kind - 2; a1 = p.d[0]; a2 = p.d[1]; b1 = p.d[2]; b2 = p.d[3]; k = p.d[4]; face = p.d[5]; }
+        T oa, da, ob, db;
+        if (axis == 0) { oa = r.ori.x; da = r.dir.x; ob = r.ori.y; db = r.dir.y; }
+        else if (axis == 1) { oa = r.ori.x; da = r.dir.x; ob = r.ori.z; db = r.dir.z; }
+        else { oa = r.ori.y; da = r.dir.y; ob = r.ori.z; db = r.dir.z; }
+        rec.p = at(r, h.t);
+        rec.normal = (axis == 0 ? V3<T>(T(0), T(0), T(1)) : axis == 1 ? V3<T>(T(0), T(1), T(0)) : V3<T>(T(1), T(0), T(0))) * face;
+        if (need_uv) {
+            T a = oa + h.t * da;
+            T b = ob + h.t * db;
+            rec.u = (a - a1) / (a2 - a1);
+            rec.v = (b - b1) / (b2 - b1);
+        }
+    }
+    xform_back(sc, in, rec.p, rec.normal);
+}
+
+// ------------------------------------------------------------------------------------------
+// textures: src/texture.rs
+// ------------------------------------------------------------------------------------------
+// Rust `as i32`: truncating, saturating, NaN -> 0
+__device__ inline int32_t as_i32(double x) { return x != x ? 0 : (x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)x)); }
+__device__ inline int32_t as_i32(float x) { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647 : (x <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)x)); }
+__device__ inline uint32_t as_u32(double x) { return x != x ? 0u : (x >= 4294967295.0 ? 4294967295u : (x <= 0.0 ? 0u : (uint32_t)x)); }
+__device__ inline uint32_t as_u32(float x) { return x != x ? 0u : (x >= 4294967296.0f ? 4294967295u : (x <= 0.0f ? 0u : (uint32_t)x)); }
+
+// src/texture.rs:139-165
+template <class T> __device__ inline T perlin_noise(const DPerlin<T>& pl, V3<T> p) {
+    T fx = rfloor(p.x), fy = rfloor(p.y), fz = rfloor(p.z);
+    T u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int32_t i = as_i32(fx), j = as_i32(fy), k = as_i32(fz);
+    T uu = u * u * (T(3) - T(2) * u);
+    T vv = v * v * (T(3) - T(2) * v);
+    T ww = w * w * (T(3) - T(2) * w);
+    T accum = T(0);
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                uint32_t idx = (uint32_t)pl.perm_x[(uint32_t)(i + di) & 255u] ^ (uint32_t)pl.perm_y[(uint32_t)(j + dj) & 255u] ^
+                               (uint32_t)pl.perm_z[(uint32_t)(k + dk) & 255u];
+                V3<T> c(pl.ranvec[idx]);
+                accum += (T(di) * uu + (T(1) - T(di)) * (T(1) - uu)) * (T(dj) * vv + (T(1) - T(dj)) * (T(1) - vv)) *
+                         (T(dk) * ww + (T(1) - T(dk)) * (T(1) - ww)) * dot(c, V3<T>(u - T(di), v - T(dj), w - T(dk)));
+            }
+    return accum;
+}
+// src/texture.rs:166-176
+template <class T> __device__ inline T perlin_turb(const DPerlin<T>& pl, V3<T> p, int depth) {
+    T accum = T(0);
+    V3<T> temp_p = p;
+    T weight = T(1);
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(pl, temp_p);
+        weight *= T(0.5);
+        temp_p = temp_p * T(2);
+    }
+    return rabs(accum);
+}
+
+template <class T> __device__ inline V3<T> texture_value(const DScene<T>& sc, uint32_t tex, T u, T v, V3<T> p) {
+    for (int guard = 0; guard < 16; guard++) {  // nested checkers: bounded descent instead of recursion
+        const DTexture<T>& t = sc.textures[tex];
+        switch (t.kind) {
+            case 0: return V3<T>(t.color);                                           // texture.rs:16-18
+            case 1: {                                                                // texture.rs:42-49
+                T sines = rsin(T(10) * p.x) * rsin(T(10) * p.y) * rsin(T(10) * p.z);
+                tex = sines < T(0) ? t.odd : t.even;
+                break;
+            }
+            case 2:                                                                  // texture.rs:27-33
+                tex = (as_i32(u / T(0.01)) % 2 == as_i32(v / T(0.01)) % 2) ? t.odd : t.even;
+                break;
+            case 3:                                                                  // texture.rs:58-60
+                return V3<T>(T(1), T(1), T(1)) * T(0.5) * (T(1) + rsin(t.scale * p.z + T(10) * perlin_turb(sc.perlins[t.table], p, 7)));
+            default: {                                                               // texture.rs:77-97
+                const DImage& im = sc.images[t.table];
+                T uc = u < T(0) ? T(0) : (u > T(1) ? T(1) : u);
+                T vc = v < T(0) ? T(0) : (v > T(1) ? T(1) : v);
+                uint32_t x = as_u32(uc * (T)im.width);
+                if (x > im.width - 1) x = im.width - 1;
+                uint32_t y = as_u32(vc * (T)im.height);
+                if (y > im.height - 1) y = im.height - 1;
+                const uint8_t* px = im.rgb + ((size_t)(im.height - 1 - y) * im.width + x) * 3;
+                T color_scale = T(1) / T(255);
+                return V3<T>((T)px[0] * color_scale, (T)px[1] * color_scale, (T)px[2] * color_scale);
+            }
+        }
+    }
+    return V3<T>(T(0), T(0), T(0));
+}
+
+}  // namespace rt

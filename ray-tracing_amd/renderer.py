@@ -1,0 +1,172 @@
+"""Host-side driver of the hot path: build a reference scene, flatten it, upload it, launch the
+render kernels, (all-reduce,) resolve.  Replaces `run_ray_tracing` of the reference
+(src/ray_tracing.rs:65-135: thread pool + mpsc + PNG) — the per-pixel work itself
+(src/ray_tracing.rs:95-118) runs in librt_hip.so.  PyTorch is used for device memory, streams and
+torch.distributed only."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import torch
+
+from . import _ffi
+from ._ffi import RT_F32, RT_F64, RtRenderParams, check
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+EARTHMAP = os.path.join(ASSETS, "earthmap.ppm")
+SCENES = ("random_scene", "random_scene_light", "two_checker_spheres", "two_perlin_spheres", "earth", "simple_light",
+          "cornell_box", "cornell_smoke", "final_scene")
+DEFAULT_SEED = 0x5EED0001
+_PRECISION = {"f32": RT_F32, "f64": RT_F64, RT_F32: RT_F32, RT_F64: RT_F64}
+
+_inited = set()
+
+
+def init(device=0):
+    """rt_init: select the GPU for this process (one process per GPU)."""
+    check(_ffi.hip().rt_init(int(device)))
+    _inited.add(int(device))
+    return _ffi.hip().rt_describe().decode()
+
+
+class HostScene:
+    """A scene graph built by the host library from one of the reference's constructors
+    (src/scenes.rs) plus its flattened RtSceneDesc.  Needs no GPU."""
+
+    def __init__(self, name, aspect_ratio=1.0, seed=DEFAULT_SEED, image_path=None):
+        lib = _ffi.host()
+        self.name, self.aspect_ratio, self.seed = name, float(aspect_ratio), int(seed)
+        img = (image_path or EARTHMAP).encode()
+        self._h = lib.rth_scene_build(name.encode(), float(aspect_ratio), int(seed), img)
+        if not self._h:
+            raise _ffi.RtError(f"rth_scene_build({name}): {lib.rth_last_error().decode()}")
+
+    @property
+    def desc_ptr(self):
+        return _ffi.host().rth_scene_desc(self._h)
+
+    @property
+    def desc(self):
+        return C.cast(self.desc_ptr, C.POINTER(_ffi.RtSceneDesc)).contents
+
+    @property
+    def num_world_prims(self):
+        return _ffi.host().rth_scene_num_world_prims(self._h)
+
+    def roundtrip_check(self):
+        n = _ffi.host().rth_scene_roundtrip_check(self._h)
+        return n, _ffi.host().rth_last_error().decode() if n else ""
+
+    def close(self):
+        if self._h:
+            _ffi.host().rth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceScene:
+    """rt_scene_create on the current device."""
+
+    def __init__(self, host_scene, device=None):
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        if self.device not in _inited:
+            init(self.device)
+        self.host = host_scene
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_ffi.hip().rt_scene_create(host_scene.desc_ptr, C.byref(h)))
+        self._h = h
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def trace_primary(self, width, height, time=0.0, medium_xi=0.5, precision="f64"):
+        """Deterministic parity probe -> (ids int32 [H,W], t float64 [H,W]); row index = y counted upward."""
+        with torch.cuda.device(self.device):
+            ids = torch.empty((height, width), dtype=torch.int32, device="cuda")
+            ts = torch.empty((height, width), dtype=torch.float64, device="cuda")
+            check(_ffi.hip().rt_trace_primary(self._h, width, height, float(time), float(medium_xi), _PRECISION[precision],
+                                              C.c_void_p(ids.data_ptr()), C.c_void_p(ts.data_ptr()), self._stream()))
+        return ids, ts
+
+    def render_into(self, accum, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
+                    max_nan_retries=64):
+        """accum: float32 CUDA tensor [H, W, 3] (row = y upward), ADDED to. stats: uint64-as-int64 tensor [4] or None."""
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.dim() == 3 and accum.shape[2] == 3
+        h, w = accum.shape[0], accum.shape[1]
+        p = RtRenderParams(w, h, int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
+                           _PRECISION[precision], 0)
+        sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), sp, self._stream()))
+
+    def sample_pixel(self, width, height, x, y, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f64"):
+        p = RtRenderParams(width, height, int(spp_begin), int(spp_count), int(max_depth), 64, int(seed), _PRECISION[precision], 0)
+        with torch.cuda.device(self.device):
+            out = torch.zeros((spp_count, 3), dtype=torch.float64, device="cuda")
+            check(_ffi.hip().rt_debug_sample_pixel(self._h, C.byref(p), int(x), int(y), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.hip().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resolve(accum, spp):
+    """ray_tracing.rs:112-117,126-128 on the device: -> uint8 CUDA tensor [H, W, 3], top row first."""
+    h, w = accum.shape[0], accum.shape[1]
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device=accum.device)
+    stream = C.c_void_p(torch.cuda.current_stream(accum.device).cuda_stream)
+    with torch.cuda.device(accum.device):
+        check(_ffi.hip().rt_resolve(C.c_void_p(accum.data_ptr()), w, h, int(spp), C.c_void_p(rgb.data_ptr()), stream))
+    return rgb
+
+
+def spp_shard(spp, rank, world_size):
+    """GPU g of N renders samples [g*spp/N, (g+1)*spp/N) of every pixel (disjoint RNG keys)."""
+    return spp * rank // world_size, spp * (rank + 1) // world_size - spp * rank // world_size
+
+
+def render(scene, width, height, spp, seed=DEFAULT_SEED, max_depth=50, precision="f32", spp_per_launch=None,
+           rank=0, world_size=1, all_reduce=None, stats=None):
+    """Render this rank's spp shard into a fresh accumulation buffer; if all_reduce is given
+    (e.g. torch.distributed.all_reduce) sum the buffers over ranks.  Returns accum [H,W,3] f32."""
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{scene.device}")
+    begin, count = spp_shard(spp, rank, world_size)
+    step = spp_per_launch or count or 1
+    s = begin
+    while s < begin + count:
+        n = min(step, begin + count - s)
+        scene.render_into(accum, s, n, seed=seed, max_depth=max_depth, precision=precision, stats=stats)
+        s += n
+    if all_reduce is not None and world_size > 1:
+        all_reduce(accum)
+    return accum
+
+
+def write_png(path, rgb):
+    """Minimal PNG writer (8-bit RGB, zlib) for the resolved image: [H, W, 3] uint8, top row first."""
+    rgb = rgb.cpu().contiguous() if hasattr(rgb, "cpu") else rgb
+    h, w = int(rgb.shape[0]), int(rgb.shape[1])
+    raw = bytes(rgb.numpy().tobytes()) if hasattr(rgb, "numpy") else bytes(rgb.tobytes())
+    rows = b"".join(b"\x00" + raw[y * w * 3:(y + 1) * w * 3] for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b""))

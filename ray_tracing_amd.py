@@ -1,0 +1,11 @@
+"""Alias: `import ray_tracing_amd` -> the package in the directory `ray-tracing_amd/` (whose
+hyphen cannot appear in an import statement)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("ray-tracing_amd")
+sys.modules[__name__] = _pkg
