@@ -83,6 +83,10 @@ class DeviceScene:
             check(_ffi.hip().rt_scene_create(host_scene.desc_ptr, C.byref(h)))
         self._h = h
 
+    @property
+    def torch_device(self):
+        return torch.device(f"cuda:{self.device}")
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -144,7 +148,7 @@ def render(scene, width, height, spp, seed=DEFAULT_SEED, max_depth=50, precision
            rank=0, world_size=1, all_reduce=None, stats=None):
     """Render this rank's spp shard into a fresh accumulation buffer; if all_reduce is given
     (e.g. torch.distributed.all_reduce) sum the buffers over ranks.  Returns accum [H,W,3] f32."""
-    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{scene.device}")
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=scene.torch_device)
     begin, count = spp_shard(spp, rank, world_size)
     step = spp_per_launch or count or 1
     s = begin

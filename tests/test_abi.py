@@ -1,0 +1,115 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares (no compute calls: this
+runs without a GPU), the ctypes mirrors have the C layout, and argument validation returns error
+codes instead of aborting."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import ray_tracing_amd as rt
+from ray_tracing_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_rt_hip_exports_every_declared_symbol():
+    names = declared_functions("rt_hip.h")
+    assert "rt_render" in names and "rt_scene_create" in names and len(names) >= 14
+    lib = C.CDLL(_ffi.LIB_HIP)
+    for n in names:
+        assert hasattr(lib, n), f"librt_hip.so does not export {n}"
+
+
+def test_rt_host_exports_every_declared_symbol():
+    names = [n for n in declared_functions("rt_host.h") if n.startswith("rth_")]
+    assert len(names) >= 7
+    lib = C.CDLL(_ffi.LIB_HOST)
+    for n in names:
+        assert hasattr(lib, n), f"librt_host.so does not export {n}"
+
+
+def test_hip_library_contains_gfx950_code_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _ffi.LIB_HIP], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump not available")
+    archs = set(re.findall(r"gfx[0-9a-f]+", out.stdout))
+    assert archs == {"gfx950"}, archs
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    # the oracle is test infrastructure: nothing under ray-tracing_amd/ may reference it
+    pkg = os.path.join(ROOT, "ray-tracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".inc", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "oracle_lib" not in text and "oracle/" not in text, os.path.join(dirpath, f)
+    for lib in (_ffi.LIB_HIP, _ffi.LIB_HOST):
+        out = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
+        assert "oracle" not in out
+
+
+def test_ctypes_mirrors_have_c_layout():
+    # sizes computed from the header's field lists (natural alignment, LP64)
+    assert C.sizeof(_ffi.RtPrim) == 8 + 80
+    assert C.sizeof(_ffi.RtMaterial) == 8 + 40
+    assert C.sizeof(_ffi.RtTexture) == 16 + 32
+    assert C.sizeof(_ffi.RtPerlin) == 3 * 1024 + 256 * 24
+    assert C.sizeof(_ffi.RtImage) == 16
+    assert C.sizeof(_ffi.RtXform) == 8 + 24
+    assert C.sizeof(_ffi.RtInstance) == 24 + 8
+    assert C.sizeof(_ffi.RtBvh) == 8 + 8 * 8
+    assert C.sizeof(_ffi.RtCamera) == 24 * 8
+    assert C.sizeof(_ffi.RtRenderParams) == 40
+    assert C.sizeof(_ffi.RtSceneDesc) == 8 + 8 * 16 - 8 + C.sizeof(_ffi.RtBvh) + 24 + C.sizeof(_ffi.RtCamera)
+    # and the host library agrees: the desc it produced reads back sensibly through the mirror
+    hs = rt.HostScene("cornell_box", 1.0)
+    d = hs.desc
+    assert d.abi_version == 1 and d.n_world == 8 and d.camera.t2 == 1.0 and d.camera.lens_radius == 0.0
+
+
+def test_validation_errors_without_gpu():
+    lib = _ffi.hip()
+    h = C.c_void_p()
+    # NULL description / NULL out
+    assert lib.rt_scene_create(None, C.byref(h)) == 1 and b"NULL" in lib.rt_last_error()
+    assert lib.rt_scene_create(None, None) == 1
+    # wrong ABI version
+    hs = rt.HostScene("cornell_box", 1.0)
+    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+    bad.abi_version = 99
+    assert lib.rt_scene_create(C.byref(bad), C.byref(h)) == 1 and b"abi_version" in lib.rt_last_error()
+    # out-of-range indices are caught before anything touches the device
+    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+    prims = (_ffi.RtPrim * bad.n_prims)(*[bad.prims[i] for i in range(bad.n_prims)])
+    prims[0].material = 10 ** 6
+    bad.prims = C.cast(prims, C.POINTER(_ffi.RtPrim))
+    assert lib.rt_scene_create(C.byref(bad), C.byref(h)) == 1 and b"material index" in lib.rt_last_error()
+    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+    world = (_ffi.RtInstance * bad.n_world)(*[bad.world[i] for i in range(bad.n_world)])
+    world[6].xform_begin = 10 ** 6
+    bad.world = C.cast(world, C.POINTER(_ffi.RtInstance))
+    assert lib.rt_scene_create(C.byref(bad), C.byref(h)) == 1 and b"xform range" in lib.rt_last_error()
+    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+    bad.n_world = 0
+    assert lib.rt_scene_create(C.byref(bad), C.byref(h)) == 1 and b"empty" in lib.rt_last_error()
+    # NULL handles
+    assert lib.rt_render(None, None, None, None, None) == 1
+    assert lib.rt_trace_primary(None, 4, 4, 0.0, 0.5, 1, None, None, None) == 1
+    assert lib.rt_resolve(None, 4, 4, 1, None, None) == 1
+    assert lib.rt_scene_destroy(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_ffi, "_hip", None)
+    monkeypatch.setattr(_ffi, "LIB_HIP", "/nonexistent/librt_hip.so")
+    with pytest.raises(rt.RtError, match="no CPU fallback"):
+        _ffi.hip()
