@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Summarise one tools/gpu_round.sh session (gpurun_out/<tag>/) into profiles/<tag>_*.
+
+  python tools/pmc_summary.py gpurun_out/r01a profiles/r01a [kernel-substring]
+
+Reads the rocprofv3 CSVs (kernel trace + the separate --pmc passes), averages every counter over the
+dispatches of the dominant kernel, and derives:
+  VALU utilisation  = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)   (active lanes per issued VALU instruction)
+  VALU busy         = SQ_ACTIVE_INST_VALU * 4 / (SQ_BUSY_CYCLES-normalised wave slots): reported as the share of
+                      wave-cycles that issued VALU: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles)
+  HBM bytes/launch  = 2 * FETCH_SIZE KiB (gfx950 correction for wide reads, MI355X_MICROARCH.md §HBM — an UPPER
+                      bound for this kernel's narrow reads) + WRITE_SIZE KiB
+  L2 hit rate       = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
+Writes <out>_summary.md, <out>_summary.json, copies the kernel-stats CSV, and updates profiles/hbm_traffic.json
+(the `traffic` field of bench.py's roofline)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    kern = sys.argv[3] if len(sys.argv) > 3 else "render_kernel"
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    counters = defaultdict(list)
+    meta = {}
+    for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*_counter_collection.csv"), recursive=True)):
+        per_dispatch = defaultdict(dict)
+        for r in csv.DictReader(open(f)):
+            if kern not in r["Kernel_Name"]:
+                continue
+            per_dispatch[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                      "Accum_VGPR_Count", "SGPR_Count")}
+        for d in per_dispatch.values():
+            for k, v in d.items():
+                counters[k].append(v)
+    avg = {k: sum(v) / len(v) for k, v in counters.items()}
+    stats_rows = []
+    for f in glob.glob(os.path.join(src, "prof_trace", "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, out + "_kernel_stats.csv")
+        stats_rows = [r for r in csv.DictReader(open(f))]
+    kstat = next((r for r in stats_rows if kern in r["Name"]), None)
+    d = {}
+    g = avg.get
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+        d["valu_utilization_pct"] = 100.0 * g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0)
+    if g("SQ_WAVE_CYCLES"):
+        for k, name in (("SQ_ACTIVE_INST_VALU", "valu_issue_share_of_wave_cycles_pct"), ("SQ_WAIT_ANY", "wait_any_share_pct"),
+                        ("SQ_WAIT_INST_ANY", "wait_inst_share_pct")):
+            if g(k) is not None:
+                d[name] = 100.0 * g(k) / g("SQ_WAVE_CYCLES")
+    if g("SQ_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
+        d["mean_waves_in_flight_per_se"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES")
+    if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
+        d["valu_insts_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+        d["l2_hit_rate_pct"] = 100.0 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        d["hbm_read_bytes_per_launch_upper"] = 2.0 * g("FETCH_SIZE") * 1024.0
+        d["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch_upper"] + d["hbm_write_bytes_per_launch"]
+        if kstat:
+            d["hbm_gbs_achieved"] = d["hbm_bytes_per_launch"] / (float(kstat["AverageNs"]) * 1e-9) / 1e9
+    summary = {"source": src, "kernel": meta.get("Kernel_Name", kern), "dispatch": meta, "kernel_stats": kstat, "counters_avg_per_launch": avg, "derived": d}
+    json.dump(summary, open(out + "_summary.json", "w"), indent=1)
+    with open(out + "_summary.md", "w") as f:
+        f.write(f"# rocprofv3 summary — {os.path.basename(out)}\n\nsource: `{src}` (tools/gpu_round.sh), kernel `{meta.get('Kernel_Name', kern)}`\n\n")
+        f.write("command per pass: `rocprofv3 [--kernel-trace --stats | --pmc <counters>] --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32`\n\n")
+        if kstat:
+            f.write(f"kernel trace: {kstat['Calls']} launches, average {float(kstat['AverageNs'])/1e6:.3f} ms "
+                    f"(min {float(kstat['MinNs'])/1e6:.3f}, max {float(kstat['MaxNs'])/1e6:.3f}), {kstat['Percentage']} % of GPU time\n\n")
+        if meta:
+            f.write("dispatch: grid {Grid_Size}, workgroup {Workgroup_Size}, VGPR {VGPR_Count} + AGPR {Accum_VGPR_Count}, SGPR {SGPR_Count}, "
+                    "LDS {LDS_Block_Size} B, scratch {Scratch_Size} B/lane\n\n".format(**meta))
+        f.write("| derived | value |\n|---|---|\n")
+        for k, v in d.items():
+            f.write(f"| {k} | {v:,.3f} |\n")
+        f.write("\n| counter (mean per launch) | value |\n|---|---|\n")
+        for k in sorted(avg):
+            f.write(f"| {k} | {avg[k]:,.0f} |\n")
+    print(open(out + "_summary.md").read())
+    if "hbm_bytes_per_launch" in d and len(sys.argv) > 4:
+        p = os.path.join(os.path.dirname(out) or ".", "hbm_traffic.json")
+        rec = json.load(open(p)) if os.path.exists(p) else {}
+        rec[sys.argv[4]] = {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "from": os.path.basename(out)}
+        json.dump(rec, open(p, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
