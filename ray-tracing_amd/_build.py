@@ -41,20 +41,23 @@ def _run(cmd):
         raise RuntimeError("build failed: " + " ".join(cmd))
 
 
-def build_hip(force=False):
+def build_hip(force=False, defines=(), out=None, tag=""):
+    """defines/out/tag: build an A/B variant library (tools/gpu_ab.py) beside the product one."""
+    global LIB_HIP
+    lib_out = out or LIB_HIP
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "rt_hip.h"))
     objs = []
     for src, flags in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", tag + ".o"))
         if force or _newer(o, [s] + headers):
-            _run([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
+            _run([HIPCC] + COMMON + flags + ["-D" + d for d in defines] + ["-c", s, "-o", o])
         objs.append(o)
-    if force or _newer(LIB_HIP, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_HIP] + objs)
-    return LIB_HIP
+    if force or _newer(lib_out, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_out] + objs)
+    return lib_out
 
 
 def build_host(force=False):

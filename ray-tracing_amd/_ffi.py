@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP = os.path.join(PKG, "librt_hip.so")
+LIB_HIP = os.environ.get("RT_HIP_LIB") or os.path.join(PKG, "librt_hip.so")  # RT_HIP_LIB: A/B variant builds (tools/gpu_ab.py)
 LIB_HOST = os.path.join(PKG, "librt_host.so")
 
 RT_F32, RT_F64 = 0, 1

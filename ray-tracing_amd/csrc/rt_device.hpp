@@ -1,18 +1,52 @@
-// rt_device.hpp — device-side path tracing for gfx950, templated on the arithmetic type T
-// (double: restates the reference's f64 arithmetic operation-for-operation; float: throughput).
+// rt_device.hpp — device-side scene layouts, math, RNG, intersection and textures for gfx950,
+// templated on the arithmetic type T (double: restates the reference's f64 arithmetic operation
+// for operation; float: throughput mode) and on a FEATURE MASK F that removes, at compile time,
+// every code path a scene cannot reach (a wave executes the union of its lanes' paths, so on this
+// machine code that is never needed is best not present: registers, I-cache).
 //
 // The reference's recursive, dyn-dispatched ray_color (src/ray_tracing.rs:11-60) becomes an
 // iterative per-lane state machine; the Object/Material/Texture/PDF traits become switches over
-// tagged records.  Every routine cites the reference lines whose arithmetic (and evaluation
-// order, strict/inclusive comparisons, NaN behaviour) it keeps.
+// tagged records.  Every routine cites the reference lines whose arithmetic (evaluation order,
+// strict/inclusive comparisons, NaN behaviour) it keeps.  Where the reference computes values it
+// then discards (sphere uv before the range test, the ONB tangents of a CosinePDF that is only
+// evaluated) they are not computed: values that are used are bit-identical.
+//
+// Branch policy (wave64): short conditionals are written as selects so the wave stays converged;
+// real branches are kept only where a whole wave commonly skips the work (sphere discriminant,
+// material kinds, BVH traversal).
 #pragma once
+#if defined(RT_HOST_SIM)
+#include "rt_hostsim_shim.hpp"  // tests/hostsim: runs these templates on the CPU against the oracle (test-only)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace rt {
 
 // ------------------------------------------------------------------------------------------
-// device layouts (built by rt_scene_create from the f64 RtSceneDesc)
+// feature mask
+// ------------------------------------------------------------------------------------------
+enum : uint32_t {
+    F_BVH = 1u << 0,         // a world / medium instance is a BvhNode tree
+    F_MEDIUM = 1u << 1,      // ConstantMedium (+ Isotropic)
+    F_MOVING = 1u << 2,      // MovingSphere
+    F_XFORM = 1u << 3,       // Translate / RotateY wrappers
+    F_SPHERE = 1u << 4,
+    F_RECT = 1u << 5,
+    F_CUBOID = 1u << 6,
+    F_METAL = 1u << 7,
+    F_DIELECTRIC = 1u << 8,  // Dielectric or FrostedDielectric
+    F_FROSTED = 1u << 9,
+    F_LIGHTS = 1u << 10,     // lights = Some(..): mixture importance sampling
+    F_TEXTURED = 1u << 11,   // any non-SolidColor texture (checker / noise / image)
+    F_UV = 1u << 12,         // some material needs the hit's (u,v)
+    F_ALL = 0xffffffffu
+};
+template <uint32_t F> __device__ constexpr bool has(uint32_t bit) { return (F & bit) != 0; }
+
+// ------------------------------------------------------------------------------------------
+// device layouts (built by rt_pack.hpp from the f64 RtSceneDesc)
 // ------------------------------------------------------------------------------------------
 template <class T> struct DPrim { T d[10]; uint32_t kind, material; };
 template <class T> struct DMaterial { T albedo[3]; T fuzz, ref_idx; uint32_t kind, texture; };
@@ -61,8 +95,8 @@ __device__ inline double sqrt_r(double x) { return ::sqrt(x); }
 __device__ inline float sqrt_r(float x) { return ::sqrtf(x); }
 __device__ inline double rsin(double x) { return ::sin(x); }
 __device__ inline float rsin(float x) { return ::sinf(x); }
-__device__ inline double rcos(double x) { return ::cos(x); }
-__device__ inline float rcos(float x) { return ::cosf(x); }
+__device__ inline void rsincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+__device__ inline void rsincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
 __device__ inline double ratan2(double y, double x) { return ::atan2(y, x); }
 __device__ inline float ratan2(float y, float x) { return ::atan2f(y, x); }
 __device__ inline double rasin(double x) { return ::asin(x); }
@@ -99,6 +133,7 @@ template <class T> __device__ inline V3<T> cross(V3<T> a, V3<T> b) {
 }
 // src/vec3.rs:30-36; a zero vector yields NaN (the reference panics) -> the sample is retried
 template <class T> __device__ inline V3<T> unit(V3<T> a) { T len = length(a); return V3<T>(a.x / len, a.y / len, a.z / len); }
+template <class T> __device__ inline V3<T> sel(bool c, V3<T> a, V3<T> b) { return V3<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 template <class T> struct Ray { V3<T> ori, dir; T time; };
 template <class T> __device__ inline V3<T> at(const Ray<T>& r, T t) { return r.ori + r.dir * t; }  // src/ray.rs:12-14
@@ -137,24 +172,24 @@ struct Rng {
         return result;
     }
     __device__ inline uint64_t next_u64() { uint64_t hi = next_u32(); uint64_t lo = next_u32(); return (hi << 32) | lo; }
+    // One "raw draw" is what gen<T>() / gen_range(T,T) consume: a u64 in f64 mode, a u32 in f32 mode.
+    __device__ inline void raw(uint64_t& r) { r = next_u64(); }
+    __device__ inline void raw(uint32_t& r) { r = next_u32(); }
     // rand 0.7.3 gen::<f64>(): 53 high bits * 2^-53;  f32: 24 high bits * 2^-24
-    __device__ inline void gen(double& out) { out = (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
-    __device__ inline void gen(float& out) { out = (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+    static __device__ inline double unit_of(uint64_t r, double) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+    static __device__ inline float unit_of(uint32_t r, float) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+    // rand 0.7.3 gen_range(lo,hi) for floats: 52 (23) fraction bits scaled into [lo,hi)
+    static __device__ inline double range_of(uint64_t r, double lo, double hi) { return lo + (hi - lo) * ((double)(r >> 12) * (1.0 / 4503599627370496.0)); }
+    static __device__ inline float range_of(uint32_t r, float lo, float hi) { return lo + (hi - lo) * ((float)(r >> 9) * (1.0f / 8388608.0f)); }
+    __device__ inline void gen(double& out) { out = unit_of(next_u64(), 0.0); }
+    __device__ inline void gen(float& out) { out = unit_of(next_u32(), 0.0f); }
     template <class T> __device__ inline T gen() { T v; gen(v); return v; }
-    // rand 0.7.3 gen_range(lo,hi) for floats: fraction scaled into [lo,hi), redrawn if it rounds to hi
+    // gen_range redraws when the scaled value rounds up to hi
     __device__ inline double gen_range(double lo, double hi) {
-        for (;;) {
-            double u = (double)(next_u64() >> 12) * (1.0 / 4503599627370496.0);
-            double v = lo + (hi - lo) * u;
-            if (v < hi) return v;
-        }
+        for (;;) { double v = range_of(next_u64(), lo, hi); if (v < hi) return v; }
     }
     __device__ inline float gen_range(float lo, float hi) {
-        for (;;) {
-            float u = (float)(next_u32() >> 9) * (1.0f / 8388608.0f);
-            float v = lo + (hi - lo) * u;
-            if (v < hi) return v;
-        }
+        for (;;) { float v = range_of(next_u32(), lo, hi); if (v < hi) return v; }
     }
     // rand 0.7.3 gen_range(0,n) for integers: widening multiply with rejection zone
     __device__ inline uint32_t gen_index(uint32_t n) {
@@ -167,6 +202,9 @@ struct Rng {
         return (uint32_t)(m >> 32);
     }
 };
+template <class T> struct RawOf;
+template <> struct RawOf<double> { typedef uint64_t type; };
+template <> struct RawOf<float> { typedef uint32_t type; };
 
 // src/vec3.rs:208-216
 template <class T> __device__ inline V3<T> random_in_unit_sphere(Rng& rng) {
@@ -184,24 +222,6 @@ template <class T> __device__ inline V3<T> random_in_unit_disk(Rng& rng) {
         if (sqlen(t) <= T(1)) return t;
     }
 }
-// src/vec3.rs:231-239
-template <class T> __device__ inline V3<T> random_cosine_direction(Rng& rng) {
-    T r1 = rng.gen<T>(); T r2 = rng.gen<T>();
-    T z = sqrt_r(T(1) - r2);
-    T phi = T(2) * Consts<T>::pi() * r1;
-    T x = rcos(phi) * sqrt_r(r2);
-    T y = rsin(phi) * sqrt_r(r2);
-    return V3<T>(x, y, z);
-}
-// src/vec3.rs:240-248
-template <class T> __device__ inline V3<T> random_to_sphere(T radius, T distance_squared, Rng& rng) {
-    T r1 = rng.gen<T>(); T r2 = rng.gen<T>();
-    T z = T(1) + r2 * (sqrt_r(T(1) - radius * radius / distance_squared) - T(1));
-    T phi = T(2) * Consts<T>::pi() * r1;
-    T x = rcos(phi) * sqrt_r(T(1) - z * z);
-    T y = rsin(phi) * sqrt_r(T(1) - z * z);
-    return V3<T>(x, y, z);
-}
 // src/vec3.rs:249-257
 template <class T> __device__ inline V3<T> reflect(V3<T> v, V3<T> n) { return v - n * T(2) * dot(v, n); }
 template <class T> __device__ inline V3<T> refract(V3<T> v, V3<T> n, T etai_over_etat) {
@@ -211,17 +231,12 @@ template <class T> __device__ inline V3<T> refract(V3<T> v, V3<T> n, T etai_over
     return r_out_perp + r_out_parallel;
 }
 
-// src/pdf.rs:5-25
-template <class T> struct ONB { V3<T> u, v, w; };
-template <class T> __device__ inline ONB<T> onb_from_w(V3<T> w_in) {
-    ONB<T> o;
-    o.w = unit(w_in);
-    V3<T> a = rabs(o.w.x) > T(0.9) ? V3<T>(T(0), T(1), T(0)) : V3<T>(T(1), T(0), T(0));
-    o.v = unit(cross(o.w, a));
-    o.u = unit(cross(o.w, o.v));
-    return o;
+// src/pdf.rs:11-24: tangents of the basis whose third axis is the UNIT vector w
+template <class T> __device__ inline void onb_tangents(V3<T> w, V3<T>& u, V3<T>& v) {
+    V3<T> a = rabs(w.x) > T(0.9) ? V3<T>(T(0), T(1), T(0)) : V3<T>(T(1), T(0), T(0));
+    v = unit(cross(w, a));
+    u = unit(cross(w, v));
 }
-template <class T> __device__ inline V3<T> onb_local(const ONB<T>& o, V3<T> a) { return o.u * a.x + o.v * a.y + o.w * a.z; }
 
 // ------------------------------------------------------------------------------------------
 // camera: src/camera.rs:57-65
@@ -244,25 +259,25 @@ template <class T> __device__ inline Ray<T> get_ray(const DCamera<T>& c, T s, T 
 // ------------------------------------------------------------------------------------------
 // primitive intersection (object-space ray).  Only t is produced during the closest-hit search;
 // p / normal / uv of the WINNING hit are computed afterwards by finish_hit with the reference's
-// formulas (the reference computes them for every candidate, including sphere uv before its range
-// check, src/objects.rs:95 — values that are discarded have no side effects).
+// formulas (the reference computes them for every candidate; values that are discarded have no
+// side effects).
 // ------------------------------------------------------------------------------------------
-// src/objects.rs:227-244, 281-298, 335-352.  axis 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x)
+// src/objects.rs:227-244, 281-298, 335-352.  axis 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x).
+// Select form: the in-plane point is computed for every lane; the comparisons are the reference's.
 template <class T>
 __device__ inline bool rect_hit(int axis, T a1, T a2, T b1, T b2, T k, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
-    T ok, dk, oa, da, ob, db;
-    if (axis == 0) { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
-    else if (axis == 1) { ok = o.y; dk = d.y; oa = o.x; da = d.x; ob = o.z; db = d.z; }
-    else { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
-    T t = (k - ok) / dk;
-    if (t >= t_min && t <= t_max) {  // inclusive
-        T a = oa + t * da;
-        T b = ob + t * db;
-        if (a >= a1 && a <= a2 && b >= b1 && b <= b2) { t_out = t; return true; }
-    }
-    return false;
+    const T ok = axis == 0 ? o.z : (axis == 1 ? o.y : o.x), dk = axis == 0 ? d.z : (axis == 1 ? d.y : d.x);
+    const T oa = axis == 2 ? o.y : o.x, da = axis == 2 ? d.y : d.x;
+    const T ob = axis == 0 ? o.y : o.z, db = axis == 0 ? d.y : d.z;
+    const T t = (k - ok) / dk;
+    const T a = oa + t * da;
+    const T b = ob + t * db;
+    const bool hit = (t >= t_min) & (t <= t_max) & (a >= a1) & (a <= a2) & (b >= b1) & (b <= b2);  // inclusive
+    t_out = hit ? t : t_out;
+    return hit;
 }
-// src/objects.rs:87-119 / 160-193 (strict comparisons)
+// src/objects.rs:87-119 / 160-193 (strict comparisons).  Both roots are evaluated; the first in
+// range wins, as in the reference.
 template <class T>
 __device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
     V3<T> oc = o - center;
@@ -272,10 +287,11 @@ __device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_
     T discriminant = half_b * half_b - a * c;
     if (discriminant > T(0)) {
         T sq = sqrt_r(discriminant);
-        T ans = (-half_b - sq) / a;
-        if (ans > t_min && ans < t_max) { t_out = ans; return true; }
-        ans = (-half_b + sq) / a;
-        if (ans > t_min && ans < t_max) { t_out = ans; return true; }
+        T r1 = (-half_b - sq) / a;
+        T r2 = (-half_b + sq) / a;
+        bool h1 = (r1 > t_min) & (r1 < t_max);
+        bool h2 = (r2 > t_min) & (r2 < t_max);
+        if (h1 | h2) { t_out = h1 ? r1 : r2; return true; }
     }
     return false;
 }
@@ -289,90 +305,99 @@ template <class T> __device__ inline void cuboid_side(const DPrim<T>& p, int i, 
     const T* mn = p.d; const T* mx = p.d + 3;
     axis = i >> 1;
     face = (i & 1) ? T(1) : T(-1);
-    if (axis == 0) { a1 = mn[0]; a2 = mx[0]; b1 = mn[1]; b2 = mx[1]; k = (i & 1) ? mx[2] : mn[2]; }
-    else if (axis == 1) { a1 = mn[0]; a2 = mx[0]; b1 = mn[2]; b2 = mx[2]; k = (i & 1) ? mx[1] : mn[1]; }
-    else { a1 = mn[1]; a2 = mx[1]; b1 = mn[2]; b2 = mx[2]; k = (i & 1) ? mx[0] : mn[0]; }
+    a1 = axis == 2 ? mn[1] : mn[0]; a2 = axis == 2 ? mx[1] : mx[0];
+    b1 = axis == 0 ? mn[1] : mn[2]; b2 = axis == 0 ? mx[1] : mx[2];
+    const int kc = 2 - axis;  // XY -> z, XZ -> y, YZ -> x
+    k = (i & 1) ? mx[kc] : mn[kc];
 }
 
 // Closest hit of ONE primitive in (t_min, t_max); side = cuboid face.
-template <class T>
+template <class T, uint32_t F>
 __device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t_min, T t_max, T& t_out, int& side) {
     side = 0;
-    switch (p.kind) {
-        case 0: return sphere_hit(V3<T>(p.d), p.d[3], o, d, t_min, t_max, t_out);
-        case 1: return sphere_hit(moving_center(p, time), p.d[8], o, d, t_min, t_max, t_out);
-        case 2: case 3: case 4:
-            return rect_hit<T>((int)p.kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
-        default: {  // cuboid: six sides in tuple order, shrinking closest (src/objects.rs:458-485)
-            bool any = false;
-            T closest = t_max;
+    const uint32_t kind = p.kind;
+    if (has<F>(F_SPHERE) && kind == 0) return sphere_hit(V3<T>(p.d), p.d[3], o, d, t_min, t_max, t_out);
+    if (has<F>(F_MOVING) && kind == 1) return sphere_hit(moving_center(p, time), p.d[8], o, d, t_min, t_max, t_out);
+    if (has<F>(F_RECT) && kind >= 2 && kind <= 4)
+        return rect_hit<T>((int)kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+    if (has<F>(F_CUBOID) && kind == 5) {  // six sides in tuple order, shrinking closest (src/objects.rs:458-485)
+        bool any = false;
+        T closest = t_max;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                int axis; T a1, a2, b1, b2, k, face;
-                cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
-                T t;
-                if (rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, t_min, closest, t)) { any = true; closest = t; side = i; }
-            }
-            t_out = closest;
-            return any;
+        for (int i = 0; i < 6; i++) {
+            int axis; T a1, a2, b1, b2, k, face;
+            cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
+            T t = closest;
+            const bool h = rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, t_min, closest, t);
+            any |= h; closest = t; side = h ? i : side;
         }
+        t_out = closest;
+        return any;
     }
+    return false;
 }
 
-// src/bvh.rs:26-58 — loose slab test, true divisions, minNum/maxNum
+// src/bvh.rs:26-58 — loose slab test, true divisions, minNum/maxNum; all three axes evaluated
 template <class T> __device__ inline bool aabb_hit(const T* mn, const T* mx, V3<T> o, V3<T> d, T t_min, T t_max) {
+    bool ok = true;
     {
         T t1 = (mn[0] - o.x) / d.x, t2 = (mx[0] - o.x) / d.x;
-        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
-        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        ok &= !(rmin(t_max, hi) <= rmax(t_min, lo));
     }
     {
         T t1 = (mn[1] - o.y) / d.y, t2 = (mx[1] - o.y) / d.y;
-        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
-        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        ok &= !(rmin(t_max, hi) <= rmax(t_min, lo));
     }
     {
         T t1 = (mn[2] - o.z) / d.z, t2 = (mx[2] - o.z) / d.z;
-        if (t1 > t2) { T s = t1; t1 = t2; t2 = s; }
-        if (rmin(t_max, t2) <= rmax(t_min, t1)) return false;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        ok &= !(rmin(t_max, hi) <= rmax(t_min, lo));
     }
-    return true;
+    return ok;
 }
 
 // Geometry of an instance: one primitive, or a threaded-BVH walk (src/bvh.rs:114-129: box test,
 // left subtree, then right subtree with t_max = best so far; strict/inclusive tie rules of the
-// leaf primitives decide equal-t replacement).
-template <class T>
+// leaf primitives decide equal-t replacement).  "while-while" form: every lane first advances
+// through internal nodes until it stands on a leaf (or is done), then the wave tests leaves
+// together, so box tests and primitive tests are not serialised against each other.
+template <class T, uint32_t F>
 __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, T time,
-                                T t_min, T t_max, T& t_out, int& prim_out, int& side_out, uint32_t& n_tests) {
-    if (geom_kind == 0) {
-        n_tests++;
+                                T t_min, T t_max, T& t_out, int& prim_out, int& side_out) {
+    if (!has<F>(F_BVH) || geom_kind == 0) {
         prim_out = (int)geom_index;
-        return prim_hit(sc.prims[geom_index], o, d, time, t_min, t_max, t_out, side_out);
+        return prim_hit<T, F>(sc.prims[geom_index], o, d, time, t_min, t_max, t_out, side_out);
     }
     bool any = false;
     T closest = t_max;
     int i = sc.bvh_root_entry[geom_index];
     const int end = sc.bvh[i].skip;
-    while (i != end) {
-        const DBvhEntry<T>& e = sc.bvh[i];
-        if (e.prim >= 0) {
-            T t; int side;
-            n_tests++;
-            if (prim_hit(sc.prims[e.prim], o, d, time, t_min, closest, t, side)) {
-                any = true; closest = t; prim_out = e.prim; side_out = side;
-            }
-            i = i + 1;
-        } else {
+    for (;;) {
+        int prim = -1;
+        while (i != end) {
+            const DBvhEntry<T>& e = sc.bvh[i];
+            prim = e.prim;
+            if (prim >= 0) break;
             i = aabb_hit(e.mn, e.mx, o, d, t_min, closest) ? i + 1 : e.skip;
         }
+        if (i == end) break;
+        T t; int side;
+        if (prim_hit<T, F>(sc.prims[prim], o, d, time, t_min, closest, t, side)) {
+            any = true; closest = t; prim_out = prim; side_out = side;
+        }
+        i = i + 1;
     }
     t_out = closest;
     return any;
 }
 
-// src/transforms.rs:15-17, 90-103: world ray -> object ray through the instance's wrapper chain
-template <class T> __device__ inline void xform_ray(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
+// src/transforms.rs:15-17, 90-103: world ray -> object ray through the instance's wrapper chain.
+// transforms.rs:34-39,124-135: pdf_value / random forward the origin (and the direction through
+// RotateY) the same way.
+template <class T, uint32_t F> __device__ inline void xform_ray(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
+    if (!has<F>(F_XFORM)) return;
     for (uint32_t j = 0; j < in.xform_count; j++) {
         const DXform<T>& x = sc.xforms[in.xform_begin + j];
         if (x.kind == 0) {
@@ -384,13 +409,9 @@ template <class T> __device__ inline void xform_ray(const DScene<T>& sc, const D
         }
     }
 }
-// transforms.rs:34-39,124-135: pdf_value / random forward only the origin through Translate and
-// origin + direction through RotateY
-template <class T> __device__ inline void xform_point_dir(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
-    xform_ray(sc, in, o, d);
-}
 // src/transforms.rs:18-21, 105-116: hit record back to world space (innermost wrapper first)
-template <class T> __device__ inline void xform_back(const DScene<T>& sc, const DInstance<T>& in, V3<T>& p, V3<T>& n) {
+template <class T, uint32_t F> __device__ inline void xform_back(const DScene<T>& sc, const DInstance<T>& in, V3<T>& p, V3<T>& n) {
+    if (!has<F>(F_XFORM)) return;
     for (int j = (int)in.xform_count - 1; j >= 0; j--) {
         const DXform<T>& x = sc.xforms[in.xform_begin + j];
         if (x.kind == 0) {
@@ -402,7 +423,8 @@ template <class T> __device__ inline void xform_back(const DScene<T>& sc, const 
         }
     }
 }
-template <class T> __device__ inline V3<T> xform_dir_back(const DScene<T>& sc, const DInstance<T>& in, V3<T> v) {
+template <class T, uint32_t F> __device__ inline V3<T> xform_dir_back(const DScene<T>& sc, const DInstance<T>& in, V3<T> v) {
+    if (!has<F>(F_XFORM)) return v;
     for (int j = (int)in.xform_count - 1; j >= 0; j--) {
         const DXform<T>& x = sc.xforms[in.xform_begin + j];
         if (x.kind == 1) {
@@ -425,43 +447,48 @@ template <class T> struct Hit {
 };
 
 // src/objects.rs:38-48 (ObjectList::hit over the world) with Translate/RotateY wrappers and
-// ConstantMedium (src/objects.rs:529-556) folded in.
-template <class T>
-__device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min, T t_max, MediumXi& mxi, Hit<T>& hit,
-                                 uint32_t& n_tests) {
+// ConstantMedium (src/objects.rs:529-556) folded in.  The instance loop is wave-uniform.  A medium
+// runs the boundary search twice through the SAME geom_hit call site (pass 0: (-max, max),
+// pass 1: (t1 + 0.0001, max)), so the traversal code exists once.
+template <class T, uint32_t F>
+__device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min, T t_max, MediumXi& mxi, Hit<T>& hit) {
     bool any = false;
     T closest = t_max;
     for (uint32_t i = 0; i < sc.n_world; i++) {
         const DInstance<T>& in = sc.world[i];
         V3<T> o = ray.ori, d = ray.dir;
-        xform_ray(sc, in, o, d);
-        T t; int prim = -1, side = 0;
-        if (!in.is_medium) {
-            if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, t_min, closest, t, prim, side, n_tests)) {
-                any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side;
-            }
-        } else {
-            T ta, tb;
-            if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, -Lim<T>::max(), Lim<T>::max(), ta, prim, side, n_tests)) {
-                int prim2, side2;
-                if (geom_hit(sc, in.geom_kind, in.geom_index, o, d, ray.time, ta + T(0.0001), Lim<T>::max(), tb, prim2, side2, n_tests)) {
-                    if (ta < t_min) ta = t_min;
-                    if (tb > closest) tb = closest;
-                    if (ta < tb) {
-                        T len = length(ray.dir);
-                        T distance_inside_boundary = (tb - ta) * len;
-                        T hit_distance = -(T(1) / in.density) * rlog(medium_xi<T>(mxi));
-                        if (hit_distance <= distance_inside_boundary) {
-                            t = ta + hit_distance / len;
-                            any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
-                            int first = (int)in.geom_index;  // boundary's first primitive in pre-order
-                            if (in.geom_kind != 0) {
-                                int e = sc.bvh_root_entry[in.geom_index];
-                                while (sc.bvh[e].prim < 0) e++;
-                                first = sc.bvh[e].prim;
-                            }
-                            hit.prim = first;
+        xform_ray<T, F>(sc, in, o, d);
+        const bool med = has<F>(F_MEDIUM) && in.is_medium;
+        T ta = T(0);
+        const int passes = med ? 2 : 1;
+#pragma nounroll
+        for (int pass = 0; pass < passes; pass++) {
+            const T lo = med ? (pass == 0 ? -Lim<T>::max() : ta + T(0.0001)) : t_min;
+            const T hi = med ? Lim<T>::max() : closest;
+            T t = hi; int prim = -1, side = 0;
+            const bool h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, ray.time, lo, hi, t, prim, side);
+            if (!med) {
+                if (h) { any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side; }
+            } else if (has<F>(F_MEDIUM)) {
+                if (!h) break;
+                if (pass == 0) { ta = t; continue; }
+                T tb = t;
+                T t1 = ta < t_min ? t_min : ta;
+                if (tb > closest) tb = closest;
+                if (t1 < tb) {
+                    T len = length(ray.dir);
+                    T distance_inside_boundary = (tb - t1) * len;
+                    T hit_distance = -(T(1) / in.density) * rlog(medium_xi<T>(mxi));
+                    if (hit_distance <= distance_inside_boundary) {
+                        t = t1 + hit_distance / len;
+                        any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
+                        int first = (int)in.geom_index;  // boundary's first primitive in pre-order
+                        if (has<F>(F_BVH) && in.geom_kind != 0) {
+                            int e = sc.bvh_root_entry[in.geom_index];
+                            while (sc.bvh[e].prim < 0) e++;
+                            first = sc.bvh[e].prim;
                         }
+                        hit.prim = first;
                     }
                 }
             }
@@ -478,31 +505,28 @@ template <class T> __device__ inline void sphere_uv(V3<T> p, T& u, T& v) {
     v = (theta + Consts<T>::pi() / T(2)) / Consts<T>::pi();
 }
 
-template <class T> struct HitRecord { T t; V3<T> p, normal; T u, v; uint32_t material; };
+template <class T> struct HitRecord { T t; V3<T> p, normal; T u, v; };
 
 // Fill the HitRecord of the winning hit (reference formulas of each primitive's `hit`).
-template <class T>
+template <class T, uint32_t F>
 __device__ inline void finish_hit(const DScene<T>& sc, const Ray<T>& ray, const Hit<T>& h, bool need_uv, HitRecord<T>& rec) {
     const DInstance<T>& in = sc.world[h.inst];
     rec.t = h.t;
-    if (h.side == 7) {  // src/objects.rs:543-550
+    rec.u = T(0); rec.v = T(0);
+    if (has<F>(F_MEDIUM) && h.side == 7) {  // src/objects.rs:543-550
         rec.p = at(ray, h.t);
         rec.normal = V3<T>(T(1), T(0), T(0));
-        rec.u = T(0); rec.v = T(0);
-        rec.material = in.phase_material;
         return;
     }
     Ray<T> r = ray;
-    xform_ray(sc, in, r.ori, r.dir);
+    xform_ray<T, F>(sc, in, r.ori, r.dir);
     const DPrim<T>& p = sc.prims[h.prim];
-    rec.material = p.material;
-    rec.u = T(0); rec.v = T(0);
-    if (p.kind <= 1) {
-        V3<T> center = p.kind == 0 ? V3<T>(p.d) : moving_center(p, ray.time);
-        T radius = p.kind == 0 ? p.d[3] : p.d[8];
-        rec.p = at(r, h.t);
-        rec.normal = (at(r, h.t) - center) / radius;
-        if (need_uv) {  // uv from the FIRST root even when the second was returned (objects.rs:94-95)
+    rec.p = at(r, h.t);
+    if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && p.kind <= 1) {
+        V3<T> center = (!has<F>(F_MOVING) || p.kind == 0) ? V3<T>(p.d) : moving_center(p, ray.time);
+        T radius = (!has<F>(F_MOVING) || p.kind == 0) ? p.d[3] : p.d[8];
+        rec.normal = (rec.p - center) / radius;
+        if (has<F>(F_UV) && need_uv) {  // uv from the FIRST root even when the second was returned (objects.rs:94-95)
             V3<T> oc = r.ori - center;
             T a = dot(r.dir, r.dir);
             T half_b = dot(oc, r.dir);
@@ -513,22 +537,20 @@ __device__ inline void finish_hit(const DScene<T>& sc, const Ray<T>& ray, const 
         }
     } else {
         int axis; T a1, a2, b1, b2, k, face;
-        if (p.kind == 5) cuboid_side(p, h.side, axis, a1, a2, b1, b2, k, face);
+        if (has<F>(F_CUBOID) && p.kind == 5) cuboid_side(p, h.side, axis, a1, a2, b1, b2, k, face);
         else { axis = (int)p.kind - 2; a1 = p.d[0]; a2 = p.d[1]; b1 = p.d[2]; b2 = p.d[3]; k = p.d[4]; face = p.d[5]; }
-        T oa, da, ob, db;
-        if (axis == 0) { oa = r.ori.x; da = r.dir.x; ob = r.ori.y; db = r.dir.y; }
-        else if (axis == 1) { oa = r.ori.x; da = r.dir.x; ob = r.ori.z; db = r.dir.z; }
-        else { oa = r.ori.y; da = r.dir.y; ob = r.ori.z; db = r.dir.z; }
-        rec.p = at(r, h.t);
-        rec.normal = (axis == 0 ? V3<T>(T(0), T(0), T(1)) : axis == 1 ? V3<T>(T(0), T(1), T(0)) : V3<T>(T(1), T(0), T(0))) * face;
-        if (need_uv) {
+        const T z0 = T(0) * face;  // the reference multiplies the axis vector by face: the zero components carry face's sign
+        rec.normal = V3<T>(axis == 2 ? face : z0, axis == 1 ? face : z0, axis == 0 ? face : z0);
+        if (has<F>(F_UV) && need_uv) {
+            const T oa = axis == 2 ? r.ori.y : r.ori.x, da = axis == 2 ? r.dir.y : r.dir.x;
+            const T ob = axis == 0 ? r.ori.y : r.ori.z, db = axis == 0 ? r.dir.y : r.dir.z;
             T a = oa + h.t * da;
             T b = ob + h.t * db;
             rec.u = (a - a1) / (a2 - a1);
             rec.v = (b - b1) / (b2 - b1);
         }
     }
-    xform_back(sc, in, rec.p, rec.normal);
+    xform_back<T, F>(sc, in, rec.p, rec.normal);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,6 +590,7 @@ template <class T> __device__ inline T perlin_turb(const DPerlin<T>& pl, V3<T> p
     T accum = T(0);
     V3<T> temp_p = p;
     T weight = T(1);
+#pragma nounroll
     for (int i = 0; i < depth; i++) {
         accum += weight * perlin_noise(pl, temp_p);
         weight *= T(0.5);
@@ -576,7 +599,8 @@ template <class T> __device__ inline T perlin_turb(const DPerlin<T>& pl, V3<T> p
     return rabs(accum);
 }
 
-template <class T> __device__ inline V3<T> texture_value(const DScene<T>& sc, uint32_t tex, T u, T v, V3<T> p) {
+template <class T, uint32_t F> __device__ inline V3<T> texture_value(const DScene<T>& sc, uint32_t tex, T u, T v, V3<T> p) {
+    if (!has<F>(F_TEXTURED)) return V3<T>(sc.textures[tex].color);  // texture.rs:16-18
     for (int guard = 0; guard < 16; guard++) {  // nested checkers: bounded descent instead of recursion
         const DTexture<T>& t = sc.textures[tex];
         switch (t.kind) {

@@ -3,14 +3,19 @@
 // reference's Rust f64 code); the f32 set is compiled with contraction enabled.
 #pragma once
 #include "rt_device.hpp"
+#include "rt_variants.hpp"
+
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 2  // register budget of the render kernel: 512 / 2 = 256 VGPR+AGPR per lane
+#endif
 
 namespace rt {
 
-template <class T> hipError_t launch_render(const DScene<T>& sc, const RenderArgs& a, float* d_accum, unsigned long long* d_stats,
-                                           hipStream_t stream);
-template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t width, uint32_t height, double time, double medium_xi,
-                                                   int32_t* d_ids, double* d_t, hipStream_t stream);
-template <class T> hipError_t launch_sample_pixel(const DScene<T>& sc, const RenderArgs& a, uint32_t x, uint32_t y, uint32_t n,
-                                                  double* d_out, hipStream_t stream);
+template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, float* d_accum,
+                                           unsigned long long* d_stats, hipStream_t stream);
+template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t features, uint32_t width, uint32_t height, double time,
+                                                   double medium_xi, int32_t* d_ids, double* d_t, hipStream_t stream);
+template <class T> hipError_t launch_sample_pixel(const DScene<T>& sc, uint32_t features, const RenderArgs& a, uint32_t x, uint32_t y,
+                                                  uint32_t n, double* d_out, hipStream_t stream);
 hipError_t launch_resolve(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb, hipStream_t stream);
 }  // namespace rt

@@ -1,0 +1,288 @@
+// rt_pack.hpp — HOST side of the device boundary: validates an RtSceneDesc (include/rt_hip.h) and
+// converts it into the device record layouts of rt_device.hpp (in host vectors; rt_hip.hip uploads
+// them).  No HIP calls here, so tests/hostsim can run the same packing on the CPU.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_device.hpp"
+
+namespace rt {
+
+inline std::string& pack_error() { static thread_local std::string e; return e; }
+inline int fail(int code, const std::string& msg) { pack_error() = msg; return code; }
+
+template <class T> struct PackedScene {
+    std::vector<DPrim<T>> prims;
+    std::vector<DMaterial<T>> materials;
+    std::vector<DTexture<T>> textures;
+    std::vector<DPerlin<T>> perlins;
+    std::vector<DXform<T>> xforms;
+    std::vector<DInstance<T>> world, lights;
+    std::vector<DBvhEntry<T>> bvh;
+    std::vector<int32_t> bvh_root_entry;
+    DScene<T> view;  // scalars filled by pack_scene; pointers by whoever owns the memory
+};
+
+inline bool texture_needs_uv(const RtSceneDesc* d, uint32_t tex, int depth) {
+    if (depth > 16) return false;
+    const RtTexture& t = d->textures[tex];
+    switch (t.kind) {
+        case RT_TEX_CHECKER_UV: case RT_TEX_IMAGE: return true;
+        case RT_TEX_CHECKER_3D: return texture_needs_uv(d, t.odd, depth + 1) || texture_needs_uv(d, t.even, depth + 1);
+        default: return false;
+    }
+}
+inline int texture_depth(const RtSceneDesc* d, uint32_t tex, int depth) {
+    if (depth > 16) return depth;
+    const RtTexture& t = d->textures[tex];
+    if (t.kind == RT_TEX_CHECKER_3D || t.kind == RT_TEX_CHECKER_UV) {
+        if (t.odd >= d->n_textures || t.even >= d->n_textures) return 99;
+        int a = texture_depth(d, t.odd, depth + 1), b = texture_depth(d, t.even, depth + 1);
+        return a > b ? a : b;
+    }
+    return depth;
+}
+
+inline int validate_instances(const RtSceneDesc* d, const RtInstance* ins, uint32_t n, const char* what) {
+    for (uint32_t i = 0; i < n; i++) {
+        const RtInstance& in = ins[i];
+        std::string at = std::string(what) + "[" + std::to_string(i) + "]";
+        if (in.geom_kind == RT_GEOM_PRIM) {
+            if (in.geom_index >= d->n_prims) return fail(RT_ERR_INVALID, at + ": primitive index out of range");
+        } else if (in.geom_kind == RT_GEOM_BVH) {
+            if (in.geom_index >= d->bvh.n_nodes) return fail(RT_ERR_INVALID, at + ": BVH root out of range");
+        } else {
+            return fail(RT_ERR_INVALID, at + ": unknown geom_kind");
+        }
+        if ((uint64_t)in.xform_begin + in.xform_count > d->n_xforms) return fail(RT_ERR_INVALID, at + ": xform range out of range");
+        if (in.is_medium) {
+            if (in.phase_material >= d->n_materials) return fail(RT_ERR_INVALID, at + ": phase material out of range");
+            if (!(in.density > 0.0)) return fail(RT_ERR_INVALID, at + ": medium density must be > 0");
+        }
+    }
+    return RT_OK;
+}
+
+inline int validate_light_ranges(const RtSceneDesc* d);
+inline int validate(const RtSceneDesc* d) {
+    if (!d) return fail(RT_ERR_INVALID, "scene description is NULL");
+    if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID, "abi_version mismatch");
+    if (d->n_world == 0) return fail(RT_ERR_INVALID, "world is empty");
+    if ((d->n_prims && !d->prims) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures) ||
+        (d->n_perlins && !d->perlins) || (d->n_images && !d->images) || (d->n_xforms && !d->xforms) || !d->world ||
+        (d->n_lights && !d->lights))
+        return fail(RT_ERR_INVALID, "NULL array with non-zero count");
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const RtTexture& t = d->textures[i];
+        if (t.kind > RT_TEX_IMAGE) return fail(RT_ERR_INVALID, "texture kind out of range");
+        if (t.kind == RT_TEX_NOISE && t.table >= d->n_perlins) return fail(RT_ERR_INVALID, "perlin index out of range");
+        if (t.kind == RT_TEX_IMAGE && t.table >= d->n_images) return fail(RT_ERR_INVALID, "image index out of range");
+        if (texture_depth(d, i, 0) > 16) return fail(RT_ERR_UNSUPPORTED, "checker textures nested deeper than 16 (or cyclic / out of range)");
+    }
+    for (uint32_t i = 0; i < d->n_images; i++)
+        if (!d->images[i].rgb || d->images[i].width == 0 || d->images[i].height == 0) return fail(RT_ERR_INVALID, "empty image");
+    for (uint32_t i = 0; i < d->n_perlins; i++)
+        for (int k = 0; k < 256; k++)
+            if ((uint32_t)d->perlins[i].perm_x[k] > 255u || (uint32_t)d->perlins[i].perm_y[k] > 255u || (uint32_t)d->perlins[i].perm_z[k] > 255u)
+                return fail(RT_ERR_INVALID, "perlin permutation entry outside 0..255");
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const RtMaterial& m = d->materials[i];
+        if (m.kind > RT_MAT_FROSTED_DIELECTRIC) return fail(RT_ERR_INVALID, "material kind out of range");
+        bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+        if (textured && m.texture >= d->n_textures) return fail(RT_ERR_INVALID, "material texture index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        if (d->prims[i].kind > RT_PRIM_CUBOID) return fail(RT_ERR_INVALID, "primitive kind out of range");
+        if (d->prims[i].material >= d->n_materials) return fail(RT_ERR_INVALID, "primitive material index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_xforms; i++)
+        if (d->xforms[i].kind > RT_XFORM_ROTATE_Y) return fail(RT_ERR_INVALID, "xform kind out of range");
+    const RtBvh& b = d->bvh;
+    if (b.n_nodes) {
+        if (!b.min_x || !b.min_y || !b.min_z || !b.max_x || !b.max_y || !b.max_z || !b.left || !b.right)
+            return fail(RT_ERR_INVALID, "NULL BVH array");
+        for (uint32_t i = 0; i < b.n_nodes; i++) {
+            const int32_t kids[2] = {b.left[i], b.right[i]};
+            for (int k = 0; k < 2; k++) {
+                if (kids[k] >= 0) {  // pre-order: a child node always follows its parent -> acyclic
+                    if ((uint32_t)kids[k] <= i || (uint32_t)kids[k] >= b.n_nodes) return fail(RT_ERR_INVALID, "BVH child node index not in pre-order range");
+                } else if ((uint32_t)(~kids[k]) >= d->n_prims) {
+                    return fail(RT_ERR_INVALID, "BVH leaf primitive index out of range");
+                }
+            }
+        }
+    }
+    int rc = validate_instances(d, d->world, d->n_world, "world");
+    if (rc) return rc;
+    if ((rc = validate_instances(d, d->lights, d->n_lights, "lights"))) return rc;
+    return validate_light_ranges(d);
+}
+
+// SoA nodes -> threaded pre-order entries (internal + leaf), see rt_device.hpp DBvhEntry.
+template <class T>
+void thread_bvh(const RtBvh& b, int32_t node, std::vector<DBvhEntry<T>>& out, std::vector<int32_t>& root_entry) {
+    // explicit stack: (node, state) — state 0 = emit node, 1 = after left, 2 = after right
+    struct Frame { int32_t node; int state; size_t entry; };
+    std::vector<Frame> st;
+    st.push_back({node, 0, 0});
+    root_entry[node] = (int32_t)out.size();
+    auto emit_leaf = [&](int32_t child) {
+        DBvhEntry<T> e;
+        for (int k = 0; k < 3; k++) { e.mn[k] = T(0); e.mx[k] = T(0); }
+        e.prim = ~child;
+        e.skip = (int32_t)out.size() + 1;
+        out.push_back(e);
+    };
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.state == 0) {
+            DBvhEntry<T> e;
+            e.mn[0] = (T)b.min_x[f.node]; e.mn[1] = (T)b.min_y[f.node]; e.mn[2] = (T)b.min_z[f.node];
+            e.mx[0] = (T)b.max_x[f.node]; e.mx[1] = (T)b.max_y[f.node]; e.mx[2] = (T)b.max_z[f.node];
+            e.prim = -1; e.skip = 0;
+            f.entry = out.size();
+            out.push_back(e);
+            f.state = 1;
+            int32_t l = b.left[f.node];
+            if (l >= 0) { st.push_back({l, 0, 0}); } else emit_leaf(l);
+        } else if (f.state == 1) {
+            f.state = 2;
+            int32_t r = b.right[f.node];
+            if (r >= 0) { st.push_back({r, 0, 0}); } else emit_leaf(r);
+        } else {
+            out[f.entry].skip = (int32_t)out.size();
+            st.pop_back();
+        }
+    }
+}
+
+template <class T> void convert_instances(const RtInstance* ins, uint32_t n, std::vector<DInstance<T>>& out) {
+    for (uint32_t i = 0; i < n; i++) {
+        DInstance<T> o;
+        o.density = (T)ins[i].density;
+        o.geom_kind = ins[i].geom_kind; o.geom_index = ins[i].geom_index;
+        o.xform_begin = ins[i].xform_begin; o.xform_count = ins[i].xform_count;
+        o.is_medium = ins[i].is_medium ? 1u : 0u; o.phase_material = ins[i].phase_material;
+        out.push_back(o);
+    }
+}
+
+
+// Light primitives that Object::random samples by gen_range need a non-empty range: rand's
+// gen_range panics on low >= high in the reference; here it is a validation error.
+inline int validate_light_ranges(const RtSceneDesc* d) {
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const RtInstance& in = d->lights[i];
+        if (in.is_medium || in.geom_kind != RT_GEOM_PRIM) continue;
+        const RtPrim& p = d->prims[in.geom_index];
+        if (p.kind >= RT_PRIM_RECT_XY && p.kind <= RT_PRIM_RECT_YZ) {
+            if (!(p.d[0] < p.d[1]) || !(p.d[2] < p.d[3])) return fail(RT_ERR_INVALID, "light rect has an empty range (gen_range needs low < high)");
+        } else if (p.kind == RT_PRIM_CUBOID) {
+            for (int k = 0; k < 3; k++)
+                if (!(p.d[k] < p.d[3 + k])) return fail(RT_ERR_INVALID, "light cuboid has an empty range (gen_range needs low < high)");
+        }
+    }
+    if (!(d->camera.t1 < d->camera.t2)) return fail(RT_ERR_INVALID, "camera shutter needs t1 < t2 (gen_range, src/camera.rs:63)");
+    return RT_OK;
+}
+
+// Which code paths the scene can reach (rt_device.hpp feature mask).
+inline uint32_t scene_features(const RtSceneDesc* d) {
+    uint32_t f = 0;
+    auto scan = [&](const RtInstance* ins, uint32_t n, bool world) {
+        for (uint32_t i = 0; i < n; i++) {
+            if (world && ins[i].geom_kind == RT_GEOM_BVH) f |= F_BVH;
+            if (world && ins[i].is_medium) f |= F_MEDIUM;
+            if (ins[i].xform_count) f |= F_XFORM;
+        }
+    };
+    scan(d->world, d->n_world, true);
+    scan(d->lights, d->n_lights, false);
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        switch (d->prims[i].kind) {
+            case RT_PRIM_SPHERE: f |= F_SPHERE; break;
+            case RT_PRIM_MOVING_SPHERE: f |= F_MOVING; break;
+            case RT_PRIM_CUBOID: f |= F_CUBOID; break;
+            default: f |= F_RECT; break;
+        }
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const RtMaterial& m = d->materials[i];
+        if (m.kind == RT_MAT_METAL) f |= F_METAL;
+        if (m.kind == RT_MAT_DIELECTRIC) f |= F_DIELECTRIC;
+        if (m.kind == RT_MAT_FROSTED_DIELECTRIC) f |= F_DIELECTRIC | F_FROSTED;
+        if (m.kind == RT_MAT_ISOTROPIC) f |= F_MEDIUM;
+        bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+        if (textured && texture_needs_uv(d, m.texture, 0)) f |= F_UV;
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++)
+        if (d->textures[i].kind != RT_TEX_SOLID) f |= F_TEXTURED;
+    if (d->n_lights) f |= F_LIGHTS;
+    return f;
+}
+
+// RtSceneDesc (f64) -> device records in T.  `d` must have passed validate().
+template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        DPrim<T> p;
+        for (int k = 0; k < 10; k++) p.d[k] = (T)d->prims[i].d[k];
+        p.kind = d->prims[i].kind; p.material = d->prims[i].material;
+        h.prims.push_back(p);
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const RtMaterial& m = d->materials[i];
+        DMaterial<T> o;
+        for (int k = 0; k < 3; k++) o.albedo[k] = (T)m.albedo[k];
+        o.fuzz = (T)m.fuzz; o.ref_idx = (T)m.ref_idx; o.texture = m.texture;
+        bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+        o.kind = m.kind | ((textured && texture_needs_uv(d, m.texture, 0)) ? 0x100u : 0u);  // bit 8: shading needs (u,v)
+        h.materials.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const RtTexture& t = d->textures[i];
+        DTexture<T> o;
+        for (int k = 0; k < 3; k++) o.color[k] = (T)t.color[k];
+        o.scale = (T)t.scale; o.kind = t.kind; o.odd = t.odd; o.even = t.even; o.table = t.table;
+        h.textures.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_perlins; i++) {
+        const RtPerlin& p = d->perlins[i];
+        DPerlin<T> o;
+        for (int k = 0; k < 256; k++) {
+            o.perm_x[k] = (uint8_t)p.perm_x[k]; o.perm_y[k] = (uint8_t)p.perm_y[k]; o.perm_z[k] = (uint8_t)p.perm_z[k];
+            for (int c = 0; c < 3; c++) o.ranvec[k][c] = (T)p.ranvec[k][c];
+        }
+        h.perlins.push_back(o);
+    }
+    for (uint32_t i = 0; i < d->n_xforms; i++) {
+        DXform<T> o;
+        for (int k = 0; k < 3; k++) o.v[k] = (T)d->xforms[i].v[k];
+        o.kind = d->xforms[i].kind;
+        h.xforms.push_back(o);
+    }
+    convert_instances<T>(d->world, d->n_world, h.world);
+    convert_instances<T>(d->lights, d->n_lights, h.lights);
+    h.bvh_root_entry.assign(d->bvh.n_nodes, -1);
+    auto add_roots = [&](const RtInstance* ins, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++)
+            if (ins[i].geom_kind == RT_GEOM_BVH && h.bvh_root_entry[ins[i].geom_index] < 0)
+                thread_bvh<T>(d->bvh, (int32_t)ins[i].geom_index, h.bvh, h.bvh_root_entry);
+    };
+    add_roots(d->world, d->n_world);
+    add_roots(d->lights, d->n_lights);
+    DScene<T>& out = h.view;
+    out.n_world = d->n_world;
+    out.n_lights = d->n_lights;
+    for (int k = 0; k < 3; k++) out.background[k] = (T)d->background[k];
+    const RtCamera& c = d->camera;
+    for (int k = 0; k < 3; k++) {
+        out.cam.origin[k] = (T)c.origin[k]; out.cam.llc[k] = (T)c.lower_left_corner[k];
+        out.cam.horizontal[k] = (T)c.horizontal[k]; out.cam.vertical[k] = (T)c.vertical[k];
+        out.cam.u[k] = (T)c.u[k]; out.cam.v[k] = (T)c.v[k]; out.cam.w[k] = (T)c.w[k];
+    }
+    out.cam.lens_radius = (T)c.lens_radius; out.cam.t1 = (T)c.t1; out.cam.t2 = (T)c.t2;
+}
+
+}  // namespace rt

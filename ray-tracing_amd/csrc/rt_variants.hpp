@@ -1,0 +1,18 @@
+// rt_variants.hpp — the feature masks the hot kernels are instantiated for, smallest first, and the
+// rule that picks one: the first mask that covers every feature of the scene (F_ALL always does).
+#pragma once
+#include "rt_device.hpp"
+
+namespace rt {
+constexpr uint32_t V_CORNELL = F_XFORM | F_SPHERE | F_RECT | F_CUBOID | F_DIELECTRIC | F_LIGHTS;           // cornell_box
+constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                                                          // cornell_smoke
+constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, perlin
+}  // namespace rt
+
+#define RT_FOR_VARIANT(features, CALL)                                       \
+    do {                                                                     \
+        if (((features) & ~rt::V_CORNELL) == 0) { CALL(rt::V_CORNELL); }     \
+        else if (((features) & ~rt::V_SMOKE) == 0) { CALL(rt::V_SMOKE); }    \
+        else if (((features) & ~rt::V_SPHERES) == 0) { CALL(rt::V_SPHERES); }\
+        else { CALL(rt::F_ALL); }                                            \
+    } while (0)

@@ -1,0 +1,171 @@
+"""The DEVICE code on the CPU (tests/hostsim: rt_device.hpp / rt_path.hpp / rt_pack.hpp compiled by g++
+with RT_HOST_SIM) against the oracle and the golden fixtures.  With T = double, primitive ids and hit
+distances agree BIT FOR BIT and every path takes the same decisions (same arithmetic order under
+-ffp-contract=off, same keyed RNG, same libm: identical cast counts); radiance agrees to 1e-12 relative,
+not bitwise, because the iterative throughput form multiplies the attenuations front to back while the
+reference's recursion (ray_tracing.rs:38-52) multiplies them back to front.  This pins the device
+templates — including every feature-mask instantiation — without a GPU; the -m gpu tests then only
+have to establish that the HIP build of the same templates behaves the same on the hardware."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from ray_tracing_amd import _ffi
+from oracle_lib import DEFAULT_SEED, OracleScene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "tests", "hostsim")
+SIM_LIB = os.path.join(SIM_DIR, "libhostsim.so")
+CSRC = os.path.join(ROOT, "ray-tracing_amd", "csrc")
+SCENES = rt.SCENES
+RAD_RTOL = 1e-12  # association of the throughput product only; decisions are identical
+
+
+def _build():
+    deps = [os.path.join(SIM_DIR, f) for f in ("sim.cpp", "rt_hostsim_shim.hpp")] + \
+           [os.path.join(CSRC, f) for f in ("rt_device.hpp", "rt_path.hpp", "rt_pack.hpp", "rt_variants.hpp")] + \
+           [os.path.join(ROOT, "include", "rt_hip.h")]
+    if os.path.exists(SIM_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(SIM_LIB) for d in deps):
+        return
+    cmd = ["g++", "-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-DRT_HOST_SIM",
+           "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-I" + SIM_DIR, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+           "-o", SIM_LIB, os.path.join(SIM_DIR, "sim.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.fixture(scope="module")
+def sim():
+    _build()
+    L = C.CDLL(SIM_LIB)
+    vp, u32, dbl = C.c_void_p, C.c_uint32, C.c_double
+    L.sim_last_error.restype = C.c_char_p
+    L.sim_scene_create.argtypes, L.sim_scene_create.restype = [vp, C.POINTER(C.c_int)], vp
+    L.sim_scene_destroy.argtypes = [vp]
+    L.sim_scene_features.argtypes, L.sim_scene_features.restype = [vp], u32
+    L.sim_trace_primary.argtypes = [vp, u32, u32, dbl, dbl, u32, C.c_int, vp, vp]
+    L.sim_sample_pixel.argtypes = [vp, C.POINTER(_ffi.RtRenderParams), u32, u32, C.c_int, vp, vp]
+    L.sim_render.argtypes = [vp, C.POINTER(_ffi.RtRenderParams), C.c_int, vp, vp]
+    return L
+
+
+class SimScene:
+    def __init__(self, L, name, aspect=1.0):
+        self.L = L
+        self.host = rt.HostScene(name, aspect)
+        rc = C.c_int()
+        self.h = L.sim_scene_create(self.host.desc_ptr, C.byref(rc))
+        assert self.h, L.sim_last_error()
+
+    def primary(self, W, H, time, xi, precision="f64", generic=False):
+        ids = np.zeros((H, W), dtype=np.int32)
+        ts = np.zeros((H, W))
+        self.L.sim_trace_primary(self.h, W, H, time, xi, 1 if precision == "f64" else 0, int(generic), ids.ctypes.data, ts.ctypes.data)
+        return ids, ts
+
+    def _params(self, W, H, s0, n, precision, max_depth=50, seed=DEFAULT_SEED):
+        return _ffi.RtRenderParams(W, H, s0, n, max_depth, 64, seed, 1 if precision == "f64" else 0, 0)
+
+    def samples(self, W, H, x, y, s0, n, precision="f64", generic=False):
+        out = np.zeros((n, 3))
+        casts = C.c_uint64(0)
+        p = self._params(W, H, s0, n, precision)
+        self.L.sim_sample_pixel(self.h, C.byref(p), x, y, int(generic), out.ctypes.data, C.byref(casts))
+        return out, casts.value
+
+    def render(self, W, H, s0, n, precision="f64", generic=False, max_depth=50):
+        acc = np.zeros((H, W, 3))
+        casts = C.c_uint64(0)
+        p = self._params(W, H, s0, n, precision, max_depth)
+        self.L.sim_render(self.h, C.byref(p), int(generic), acc.ctypes.data, C.byref(casts))
+        return acc, casts.value
+
+    def __del__(self):
+        try:
+            self.L.sim_scene_destroy(self.h)
+        except Exception:
+            pass
+
+
+def test_feature_masks(sim):
+    F = dict(BVH=1, MEDIUM=2, MOVING=4, XFORM=8, SPHERE=16, RECT=32, CUBOID=64, METAL=128, DIELECTRIC=256, FROSTED=512, LIGHTS=1024,
+             TEXTURED=2048, UV=4096)
+    def f(name):
+        sc = SimScene(sim, name)  # keep the scene alive across the call
+        return sim.sim_scene_features(sc.h)
+
+    assert f("cornell_box") == F["XFORM"] | F["SPHERE"] | F["RECT"] | F["CUBOID"] | F["DIELECTRIC"] | F["LIGHTS"]
+    assert f("cornell_smoke") == F["XFORM"] | F["RECT"] | F["CUBOID"] | F["MEDIUM"]
+    assert f("random_scene") == F["BVH"] | F["SPHERE"] | F["MOVING"] | F["METAL"] | F["DIELECTRIC"] | F["TEXTURED"]
+    assert f("earth") == F["SPHERE"] | F["TEXTURED"] | F["UV"]
+    fs = f("final_scene")
+    assert fs & F["BVH"] and fs & F["MEDIUM"] and fs & F["LIGHTS"] and fs & F["UV"] and fs & F["MOVING"] and fs & F["CUBOID"]
+    assert f("random_scene_light") & F["FROSTED"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_sim_primary_bit_exact(sim, name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"primary_{name}.npz"))
+    sc = SimScene(sim, name)
+    for generic in (False, True):
+        for tag, tm in (("t0", 0.0), ("t05", 0.5)):
+            ids, ts = sc.primary(64, 64, tm, float(g["medium_xi"]), "f64", generic)
+            assert np.array_equal(ids, g[f"ids_{tag}"]), (name, generic, tag)
+            assert np.array_equal(ts, g[f"t_{tag}"]), (name, generic, tag)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_sim_samples_bit_exact(sim, name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"samples_{name}.npz"))["rgb"]
+    sc = SimScene(sim, name)
+    for generic in (False, True):
+        got, casts = sc.samples(48, 48, 20, 13, 0, 64, "f64", generic)
+        assert np.allclose(got, g, rtol=RAD_RTOL, atol=0), (name, generic, np.abs(got - g).max())
+        assert casts >= 64
+
+
+@pytest.mark.parametrize("name", ("cornell_box", "cornell_smoke", "random_scene", "final_scene", "simple_light", "random_scene_light"))
+def test_sim_frame_equals_oracle(sim, name):
+    W, H, s0, n = 28, 20, 5, 3
+    sc = SimScene(sim, name, W / H)
+    got, casts = sc.render(W, H, s0, n)
+    ref, cnt = OracleScene(name, W / H).render(W, H, s0, n, threads=8)
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0), np.abs(got - ref).max()
+    assert casts == cnt["casts"]
+
+
+def test_sim_f32_is_close(sim, golden_dir):
+    # the f32 instantiation on the CPU: same ids almost everywhere, t within 5e-4, sane radiance
+    for name in ("cornell_box", "final_scene"):
+        g = np.load(os.path.join(golden_dir, f"primary_{name}.npz"))
+        sc = SimScene(sim, name)
+        ids, ts = sc.primary(64, 64, 0.0, 0.5, "f32")
+        same = ids == g["ids_t0"]
+        assert same.mean() > 0.995
+        hit = same & (ids >= 0)
+        assert (np.abs(ts[hit] - g["t_t0"][hit]) / g["t_t0"][hit]).max() < 5e-4
+        a64, _ = sc.render(16, 16, 0, 64, "f64")
+        a32, _ = sc.render(16, 16, 0, 64, "f32")
+        assert np.isfinite(a32).all() and abs(a32.mean() - a64.mean()) < 0.25 * a64.mean()
+
+
+def test_sim_depth_limits(sim):
+    sc = SimScene(sim, "cornell_box")
+    assert sc.render(8, 8, 0, 4, max_depth=0)[0].max() == 0.0
+    a, _ = sc.render(16, 16, 0, 4, max_depth=1)
+    assert set(np.unique(a).tolist()) <= {0.0, 15.0, 30.0, 45.0, 60.0}
+
+
+def test_light_with_empty_range_is_rejected(sim):
+    hs = rt.HostScene("cornell_box", 1.0)
+    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+    prims = (_ffi.RtPrim * bad.n_prims)(*[bad.prims[i] for i in range(bad.n_prims)])
+    li = bad.lights[0].geom_index
+    prims[li].d[1] = prims[li].d[0]  # x2 == x1: gen_range(low, high) panics in the reference
+    bad.prims = C.cast(prims, C.POINTER(_ffi.RtPrim))
+    rc = C.c_int()
+    assert not sim.sim_scene_create(C.byref(bad), C.byref(rc)) and rc.value == 1 and b"empty range" in sim.sim_last_error()
