@@ -6,8 +6,8 @@
       bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE configs[1]): cornell_box, 1024x1024, mixture-PDF light importance sampling, depth 50.
-A STEP is one rt_render launch over the whole frame adding `--spp-per-step` (64) samples to every pixel;
-the default K = 16 steps are exactly the 1024 spp of the config.  Scene and accumulation buffer are
+A STEP is one rt_render launch over the whole frame adding `--spp-per-step` (256) samples to every pixel;
+the default K = 4 steps are exactly the 1024 spp of the config.  Scene and accumulation buffer are
 resident in HBM before the timed region.  With N > 1 every rank renders its own disjoint sample indices
 of the full frame (weak scaling: per-GPU work fixed) and the float accumulation buffers are summed by
 ONE RCCL all-reduce inside the timed region (SURVEY §8 e).
@@ -53,12 +53,12 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--precision", default="f64", choices=("f64", "f32"))
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -149,6 +149,7 @@ static int make_args(const RtRenderParams* p, rt::RenderArgs& a) {
     if (p->width < 2 || p->height < 2 || (uint64_t)p->width * p->height > 0x7fffffffull) return fail(RT_ERR_INVALID, "width/height must be >= 2 and width*height < 2^31");
     if (p->max_depth < 0) return fail(RT_ERR_INVALID, "max_depth must be >= 0");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(RT_ERR_INVALID, "spp range overflows 32 bits");
+    if (p->spp_count >= (1u << 26)) return fail(RT_ERR_INVALID, "spp_count per launch must be < 2^26 (split the range over launches)");
     a.width = p->width; a.height = p->height; a.spp_begin = p->spp_begin; a.spp_count = p->spp_count;
     a.max_depth = p->max_depth; a.max_nan_retries = p->max_nan_retries ? p->max_nan_retries : 64u; a.seed = p->seed;
     return RT_OK;

@@ -5,10 +5,6 @@
 #include "rt_device.hpp"
 #include "rt_variants.hpp"
 
-#ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 2  // register budget of the render kernel: 512 / 2 = 256 VGPR+AGPR per lane
-#endif
-
 namespace rt {
 
 template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, float* d_accum,

@@ -7,6 +7,17 @@ namespace rt {
 constexpr uint32_t V_CORNELL = F_XFORM | F_SPHERE | F_RECT | F_CUBOID | F_DIELECTRIC | F_LIGHTS;           // cornell_box
 constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                                                          // cornell_smoke
 constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, perlin
+
+// Register budget of the render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
+// SIMD: 2 -> 256, 3 -> 168, 4 -> 128).  Chosen from measurements (profiles/): the no-BVH f64
+// instantiations fit 168 without spilling and run 23 % faster at 3 waves than at 2.
+template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
+#ifdef RT_WAVES_PER_SIMD
+    return RT_WAVES_PER_SIMD;
+#else
+    return sizeof(T) == 8 ? (((F & F_BVH) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
+#endif
+}
 }  // namespace rt
 
 #define RT_FOR_VARIANT(features, CALL)                                       \

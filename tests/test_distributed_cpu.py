@@ -68,7 +68,7 @@ def test_two_rank_gloo_render_equals_single_rank(tmp_path):
 
 def test_bench_step_ranges_are_disjoint():
     # bench.py: step i of rank r covers [(i*world + r)*S, +S)
-    S, K = 64, 16
+    S, K = 256, 4
     for world in (1, 2, 4, 8):
         starts = sorted((i * world + r) * S for i in range(K) for r in range(world))
         assert starts == list(range(0, S * K * world, S))
