@@ -118,7 +118,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun the RCCL path runs even at N = 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
@@ -131,7 +132,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -151,7 +152,7 @@ def main():
 
     def timed(precision, K, Wm, first):
         run_steps(first, Wm, precision)          # untimed warm-up (distinct sample indices)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(accum.clone())       # warm RCCL up as well
         accum.zero_()
         stats.zero_()
@@ -159,12 +160,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         run_steps(first + Wm, K, precision, events)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(accum)               # the path's one exchange step (sum of accumulation buffers)
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         launch_ms = [e0.elapsed_time(e1) for e0, e1 in events]
         return tmax.item(), launch_ms
@@ -233,7 +234,7 @@ def main():
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
