@@ -169,3 +169,17 @@ def test_light_with_empty_range_is_rejected(sim):
     bad.prims = C.cast(prims, C.POINTER(_ffi.RtPrim))
     rc = C.c_int()
     assert not sim.sim_scene_create(C.byref(bad), C.byref(rc)) and rc.value == 1 and b"empty range" in sim.sim_last_error()
+
+
+@pytest.mark.parametrize("name", ("random_scene", "final_scene", "random_scene_light"))
+def test_sim_bvh_cull_is_invisible(sim, name):
+    # The device walks BVHs with a division-free node classification + conservative culling (rt_device.hpp
+    # aabb_classify) instead of the reference's loose test on every node: ids and t must still be bit-exact
+    # on a dense probe (many grazing rays along silhouettes), for two times and a non-square aspect.
+    W, H = 224, 126
+    sc = SimScene(sim, name, W / H)
+    oc = OracleScene(name, W / H)
+    for tm in (0.0, 0.73):
+        ids, ts = sc.primary(W, H, tm, 0.5)
+        oi, ot = oc.trace_primary(W, H, tm, 0.5)
+        assert np.array_equal(ids, oi) and np.array_equal(ts, ot)
