@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH_SHORT="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32"
+BENCH_SHORT="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32 ${BENCH_ARGS:-}"
 
 fatal() { case $1 in 124|137|134|139|-6|-11) echo "step '$2' ended with $1: stopping" | tee -a "$OUT/status.txt"; exit "$1";; esac; }
 step() {  # step <name> <seconds> <cmd...>
