@@ -59,6 +59,9 @@ template <class T> struct DInstance { T density; uint32_t geom_kind, geom_index,
 // stack when internal nodes AND leaves are laid out in pre-order and each internal node knows
 // where its subtree ends: box hit -> next entry, box miss -> skip.  prim >= 0 marks a leaf.
 template <class T> struct DBvhEntry { T mn[3], mx[3]; int32_t skip, prim; };
+// Compact copy of a BVH entry for the division-free node classification: the box in f32, rounded
+// OUTWARD (so it contains the exact box), same skip/prim links.  32 bytes: this is what is staged in LDS.
+struct alignas(16) DBvhLite { float mn[3], mx[3]; int32_t skip, prim; };
 template <class T> struct DCamera { T origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3]; T lens_radius, t1, t2; };
 
 template <class T> struct DScene {
@@ -72,6 +75,9 @@ template <class T> struct DScene {
     const DInstance<T>* lights;
     const DBvhEntry<T>* bvh;
     const int32_t* bvh_root_entry;  // node index (RtBvh numbering) -> entry index, for instance roots
+    const DBvhLite* bvh_lite;       // same indexing as bvh
+    const DBvhLite* bvh_lds;        // entries [0, n_bvh_lds) of bvh_lite staged in LDS by the render kernel (else n_bvh_lds = 0)
+    uint32_t n_bvh, n_bvh_lds;
     uint32_t n_world, n_lights;
     T background[3];
     DCamera<T> cam;
@@ -316,8 +322,12 @@ template <class T, uint32_t F>
 __device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t_min, T t_max, T& t_out, int& side) {
     side = 0;
     const uint32_t kind = p.kind;
-    if (has<F>(F_SPHERE) && kind == 0) return sphere_hit(V3<T>(p.d), p.d[3], o, d, t_min, t_max, t_out);
-    if (has<F>(F_MOVING) && kind == 1) return sphere_hit(moving_center(p, time), p.d[8], o, d, t_min, t_max, t_out);
+    if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && kind <= 1) {  // one sphere test for both kinds: mixed leaves stay converged
+        V3<T> center(p.d);
+        T radius = p.d[3];
+        if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
+        return sphere_hit(center, radius, o, d, t_min, t_max, t_out);
+    }
     if (has<F>(F_RECT) && kind >= 2 && kind <= 4)
         return rect_hit<T>((int)kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
     if (has<F>(F_CUBOID) && kind == 5) {  // six sides in tuple order, shrinking closest (src/objects.rs:458-485)
@@ -358,42 +368,61 @@ template <class T> __device__ inline bool aabb_hit(const T* mn, const T* mx, V3<
     return ok;
 }
 
-// Cheap classification of a node against the ray, WITHOUT divisions: 1 = the reference's loose test
-// certainly passes, 0 = no primitive below this node can be hit inside (t_min, t_max) (cull),
-// 2 = too close to call -> the caller evaluates aabb_hit exactly.
-//   a = (bound - o) * (1/d) differs from the reference's (bound - o) / d by <= 4 ulp.  With
-//   gap = min(t_max, hi_xyz) - max(t_min, lo_xyz)  (the proper slab intersection):
-//   gap >  tol: every axis overlaps (t_min,t_max) by more than any rounding -> the per-axis loose
-//               test passes, exactly as in the reference -> descend;
+// Cheap classification of a node against the ray, in f32 and WITHOUT divisions: 1 = the reference's
+// loose test certainly passes, 0 = no primitive below this node can be hit inside (t_min, t_max)
+// (cull), 2 = too close to call -> the caller evaluates aabb_hit exactly (in T, true divisions).
+//   Inputs: the node's box rounded outward to f32, the ray origin and reciprocal direction rounded
+//   to f32.  a = (bound - o) * (1/d) then differs from the reference's (bound - o) / d by a relative
+//   error < 5e-7 of (|o| + |bound|)|1/d|.  With gap = min(t_max, hi_xyz) - max(t_min, lo_xyz) (the
+//   proper slab intersection) and tol = 2^-16 (|o| + B)|1/d|  (B = largest |coordinate| of the tree):
+//   gap >  tol: every axis overlaps (t_min,t_max) by more than all rounding -> the per-axis loose
+//               test on the exact box passes, exactly as in the reference -> descend;
 //   gap < -tol: a hit at t in (t_min,t_max) below this node would lie inside the node's box, i.e.
-//               inside every slab interval up to the hit point's rounding error, which `tol`
-//               (the box padded by 2^-20 of the coordinate scale, in t units) exceeds by > 2^30
-//               -> skipping the subtree cannot change the closest hit, whatever the loose test says;
-//   otherwise (grazing, axis-parallel rays with 1/d = inf, NaN): decided by the exact test.
+//               inside every slab interval up to the hit point's rounding error (~1e-13 in f64),
+//               which tol exceeds by orders of magnitude -> skipping the subtree cannot change the
+//               closest hit, whatever the loose test says;
+//   otherwise (grazing rays, axis-parallel rays with 1/d = inf, NaN, f32 overflow): the exact test.
 // The reference's loose test lets through ~27 % of a 480-node tree per ray; the cull visits the few
 // nodes the ray actually crosses and still returns the identical hit (ids and t bit-exact).
-template <class T> __device__ inline int aabb_classify(const T* mn, const T* mx, V3<T> o, V3<T> inv, T t_min, T t_max, T tol) {
-    const T x1 = (mn[0] - o.x) * inv.x, x2 = (mx[0] - o.x) * inv.x;
-    const T y1 = (mn[1] - o.y) * inv.y, y2 = (mx[1] - o.y) * inv.y;
-    const T z1 = (mn[2] - o.z) * inv.z, z2 = (mx[2] - o.z) * inv.z;
-    const T lx = x1 < x2 ? x1 : x2, hx = x1 < x2 ? x2 : x1;
-    const T ly = y1 < y2 ? y1 : y2, hy = y1 < y2 ? y2 : y1;
-    const T lz = z1 < z2 ? z1 : z2, hz = z1 < z2 ? z2 : z1;
-    T enter = lx > ly ? lx : ly; enter = enter > lz ? enter : lz; enter = enter > t_min ? enter : t_min;
-    T exit = hx < hy ? hx : hy; exit = exit < hz ? exit : hz; exit = exit < t_max ? exit : t_max;
-    const T gap = exit - enter;
+__device__ inline int aabb_classify(const DBvhLite& e, float ox, float oy, float oz, float ix, float iy, float iz, float t_min,
+                                    float t_max, float tol) {
+    const float x1 = (e.mn[0] - ox) * ix, x2 = (e.mx[0] - ox) * ix;
+    const float y1 = (e.mn[1] - oy) * iy, y2 = (e.mx[1] - oy) * iy;
+    const float z1 = (e.mn[2] - oz) * iz, z2 = (e.mx[2] - oz) * iz;
+    const float lx = x1 < x2 ? x1 : x2, hx = x1 < x2 ? x2 : x1;
+    const float ly = y1 < y2 ? y1 : y2, hy = y1 < y2 ? y2 : y1;
+    const float lz = z1 < z2 ? z1 : z2, hz = z1 < z2 ? z2 : z1;
+    float enter = lx > ly ? lx : ly; enter = enter > lz ? enter : lz; enter = enter > t_min ? enter : t_min;
+    float exit = hx < hy ? hx : hy; exit = exit < hz ? exit : hz; exit = exit < t_max ? exit : t_max;
+    const float gap = exit - enter;
     return gap > tol ? 1 : (gap < -tol ? 0 : 2);
 }
-template <class T> struct CullEps;
-template <> struct CullEps<double> { static __device__ constexpr double rel() { return 9.5367431640625e-07; } };  // 2^-20
-template <> struct CullEps<float> { static __device__ constexpr float rel() { return 9.765625e-04f; } };          // 2^-10
+
+// Entry i of the table staged in LDS.  The generic pointer is narrowed to the LDS address space by hand
+// (its low 32 bits are the LDS offset): the optimiser cannot infer it through DScene, and a flat load
+// would wait on both memory counters.
+__device__ inline DBvhLite lds_entry(const DBvhLite* table, int i) {
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__)
+    return table[i];
+#else
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u4* lds_ptr;
+    lds_ptr p = (lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)table + 2 * i;
+    const u4 a = p[0], b = p[1];
+    DBvhLite e;
+    e.mn[0] = __uint_as_float(a.x); e.mn[1] = __uint_as_float(a.y); e.mn[2] = __uint_as_float(a.z); e.mx[0] = __uint_as_float(a.w);
+    e.mx[1] = __uint_as_float(b.x); e.mx[2] = __uint_as_float(b.y); e.skip = (int32_t)b.z; e.prim = (int32_t)b.w;
+    return e;
+#endif
+}
 
 // Geometry of an instance: one primitive, or a threaded-BVH walk (src/bvh.rs:114-129: box test,
 // left subtree, then right subtree with t_max = best so far; strict/inclusive tie rules of the
 // leaf primitives decide equal-t replacement; the visiting ORDER is the reference's, so ties
 // resolve identically).  "while-while" form: every lane first advances through internal nodes
 // until it stands on a leaf (or is done), then the wave tests leaves together, so box tests and
-// primitive tests are not serialised against each other.
+// primitive tests are not serialised against each other.  Node records come from LDS for the
+// entries the render kernel staged there, else from global memory (L2).
 template <class T, uint32_t F>
 __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, T time,
                                 T t_min, T t_max, T& t_out, int& prim_out, int& side_out) {
@@ -404,31 +433,40 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
     bool any = false;
     T closest = t_max;
     int i = sc.bvh_root_entry[geom_index];
-    const int end = sc.bvh[i].skip;
-    // per-ray constants of the division-free node classification
-    const V3<T> inv(T(1) / d.x, T(1) / d.y, T(1) / d.z);
-    T tol;
+    const int n_lds = (int)sc.n_bvh_lds;
+    // per-ray constants of the node classification
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+    const float tminf = (float)t_min;
+    float tol;
+    int end;
     {
-        const DBvhEntry<T>& root = sc.bvh[i];
-        T B = rabs(root.mn[0]);
-        B = rmax(B, rabs(root.mn[1])); B = rmax(B, rabs(root.mn[2]));
-        B = rmax(B, rabs(root.mx[0])); B = rmax(B, rabs(root.mx[1])); B = rmax(B, rabs(root.mx[2]));
-        const T tiny = T(1e-30);
-        const T px = (rabs(o.x) + B + tiny) * CullEps<T>::rel() * rabs(inv.x);
-        const T py = (rabs(o.y) + B + tiny) * CullEps<T>::rel() * rabs(inv.y);
-        const T pz = (rabs(o.z) + B + tiny) * CullEps<T>::rel() * rabs(inv.z);
+        const DBvhLite& root = sc.bvh_lite[i];
+        end = root.skip;
+        float B = fabsf(root.mn[0]);
+        B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
+        B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
+        const float rel = 1.52587890625e-05f, tiny = 1e-30f;  // 2^-16
+        const float px = (fabsf(ox) + B + tiny) * rel * fabsf(ix);
+        const float py = (fabsf(oy) + B + tiny) * rel * fabsf(iy);
+        const float pz = (fabsf(oz) + B + tiny) * rel * fabsf(iz);
         tol = px > py ? px : py; tol = tol > pz ? tol : pz;
-        if (!(tol == tol)) tol = Lim<T>::max();  // NaN -> nothing is certain -> exact tests
+        if (!(tol == tol)) tol = 3.402823466e+38f;  // NaN -> nothing is certain -> exact tests
     }
     for (;;) {
         int prim = -1;
+        float closestf = (float)closest;
         while (i != end) {
-            const DBvhEntry<T>& e = sc.bvh[i];
+            DBvhLite e;
+            if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
             prim = e.prim;
             if (prim >= 0) break;
-            const int c = aabb_classify(e.mn, e.mx, o, inv, t_min, closest, tol);
+            const int c = aabb_classify(e, ox, oy, oz, ix, iy, iz, tminf, closestf, tol);
             bool pass = c == 1;
-            if (c == 2) pass = aabb_hit(e.mn, e.mx, o, d, t_min, closest);  // rare: the reference's exact decision
+            if (c == 2) {  // rare: the reference's exact decision on the exact box
+                const DBvhEntry<T>& ex = sc.bvh[i];
+                pass = aabb_hit(ex.mn, ex.mx, o, d, t_min, closest);
+            }
             i = pass ? i + 1 : e.skip;
         }
         if (i == end) break;

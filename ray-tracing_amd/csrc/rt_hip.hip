@@ -60,6 +60,7 @@ int build_device_scene(RtScene* sc, const RtSceneDesc* d, const rt::DImage* d_im
     if ((rc = upload(sc, h.lights, &out.lights))) return rc;
     if ((rc = upload(sc, h.bvh, &out.bvh))) return rc;
     if ((rc = upload(sc, h.bvh_root_entry, &out.bvh_root_entry))) return rc;
+    if ((rc = upload(sc, h.bvh_lite, &out.bvh_lite))) return rc;
     out.images = d_images;
     return RT_OK;
 }

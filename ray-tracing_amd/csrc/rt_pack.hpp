@@ -2,6 +2,7 @@
 // converts it into the device record layouts of rt_device.hpp (in host vectors; rt_hip.hip uploads
 // them).  No HIP calls here, so tests/hostsim can run the same packing on the CPU.
 #pragma once
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@ template <class T> struct PackedScene {
     std::vector<DInstance<T>> world, lights;
     std::vector<DBvhEntry<T>> bvh;
     std::vector<int32_t> bvh_root_entry;
+    std::vector<DBvhLite> bvh_lite;
     DScene<T> view;  // scalars filled by pack_scene; pointers by whoever owns the memory
 };
 
@@ -272,7 +274,19 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     };
     add_roots(d->world, d->n_world);
     add_roots(d->lights, d->n_lights);
+    // f32 copies of the boxes, rounded outward so that they contain the exact boxes
+    auto down = [](T x) { float f = (float)x; return ((T)f > x) ? std::nextafterf(f, -INFINITY) : f; };
+    auto up = [](T x) { float f = (float)x; return ((T)f < x) ? std::nextafterf(f, INFINITY) : f; };
+    for (const DBvhEntry<T>& e : h.bvh) {
+        DBvhLite l;
+        for (int k = 0; k < 3; k++) { l.mn[k] = down(e.mn[k]); l.mx[k] = up(e.mx[k]); }
+        l.skip = e.skip; l.prim = e.prim;
+        h.bvh_lite.push_back(l);
+    }
     DScene<T>& out = h.view;
+    out.n_bvh = (uint32_t)h.bvh.size();
+    out.n_bvh_lds = 0;
+    out.bvh_lds = nullptr;
     out.n_world = d->n_world;
     out.n_lights = d->n_lights;
     for (int k = 0; k < 3; k++) out.background[k] = (T)d->background[k];

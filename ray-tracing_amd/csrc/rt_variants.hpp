@@ -18,6 +18,15 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
     return sizeof(T) == 8 ? (((F & F_BVH) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
 #endif
 }
+// LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
+// register budget does: f64 2 blocks x (64 KB + 6 KB tile sums), f32 3 blocks x (44 KB + 6 KB) of 160 KB.
+template <class T> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
+#ifdef RT_LDS_BVH_ENTRIES
+    return RT_LDS_BVH_ENTRIES;
+#else
+    return sizeof(T) == 8 ? 2048u : 1408u;
+#endif
+}
 }  // namespace rt
 
 #define RT_FOR_VARIANT(features, CALL)                                       \

@@ -15,11 +15,16 @@
 namespace {
 template <class T> struct Side {
     rt::PackedScene<T> p;
+    std::vector<rt::DBvhLite> lds_copy;
     void seal(const rt::DImage* images) {
         rt::DScene<T>& v = p.view;
         v.prims = p.prims.data(); v.materials = p.materials.data(); v.textures = p.textures.data(); v.perlins = p.perlins.data();
         v.xforms = p.xforms.data(); v.world = p.world.data(); v.lights = p.lights.data(); v.bvh = p.bvh.data();
         v.bvh_root_entry = p.bvh_root_entry.data(); v.images = images;
+        v.bvh_lite = p.bvh_lite.data();
+        // exercise both sources of node records: the first half "staged" (a second copy), the rest "global"
+        lds_copy.assign(p.bvh_lite.begin(), p.bvh_lite.begin() + p.bvh_lite.size() / 2);
+        v.bvh_lds = lds_copy.data(); v.n_bvh_lds = (uint32_t)lds_copy.size();
     }
 };
 struct SimScene {
