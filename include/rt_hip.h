@@ -184,8 +184,11 @@ typedef struct RtRenderParams {
     uint32_t max_nan_retries; /* cap on the NaN retry loop of ray_tracing.rs:102-110 (0 -> 64) */
     uint64_t seed;
     uint32_t precision;       /* RtPrecision */
-    uint32_t reserved;
+    uint32_t flags;           /* RtRenderFlags, 0 = default */
 } RtRenderParams;
+/* RT_RENDER_NO_SORT: use the wave-level kernel even where the block-sorted one applies (same samples, same
+ * sums up to the order of f64 additions; for A/B measurements and tests). */
+enum RtRenderFlags { RT_RENDER_NO_SORT = 1 };
 
 /* d_stats: 4 x uint64 counters, ADDED to by rt_render:
  * [0] accepted samples, [1] ray casts (world.hit calls), [2] NaN retries, [3] samples dropped at the retry cap */

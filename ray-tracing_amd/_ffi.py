@@ -17,7 +17,7 @@ class RtRenderParams(C.Structure):
         ("spp_begin", C.c_uint32), ("spp_count", C.c_uint32),
         ("max_depth", C.c_int32), ("max_nan_retries", C.c_uint32),
         ("seed", C.c_uint64),
-        ("precision", C.c_uint32), ("reserved", C.c_uint32),
+        ("precision", C.c_uint32), ("flags", C.c_uint32),
     ]
 
 

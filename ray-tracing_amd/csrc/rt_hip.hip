@@ -163,8 +163,8 @@ int rt_render(RtScene* scene, const RtRenderParams* params, float* d_accum, uint
     if ((rc = make_args(params, a))) return rc;
     if (!d_accum) return fail(RT_ERR_INVALID, "d_accum is NULL");
     if (a.spp_count == 0) return RT_OK;
-    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
-    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
+    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, (params->flags & RT_RENDER_NO_SORT) != 0, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
+    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, (params->flags & RT_RENDER_NO_SORT) != 0, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
     else return fail(RT_ERR_INVALID, "unknown precision");
     return RT_OK;
 }

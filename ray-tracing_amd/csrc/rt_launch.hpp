@@ -7,7 +7,7 @@
 
 namespace rt {
 
-template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, float* d_accum,
+template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, bool no_sort, float* d_accum,
                                            unsigned long long* d_stats, hipStream_t stream);
 template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t features, uint32_t width, uint32_t height, double time,
                                                    double medium_xi, int32_t* d_ids, double* d_t, hipStream_t stream);

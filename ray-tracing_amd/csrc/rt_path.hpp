@@ -176,13 +176,22 @@ __device__ inline void lambertian_sample(const DScene<T>& sc, const HitRecord<T>
     dir_out = dir;
 }
 
-// One segment of ray_color (src/ray_tracing.rs:19-59): cast, emit, scatter, pick the next
-// direction.  Returns true when the path has terminated (st.L is final).
+// One segment of ray_color (src/ray_tracing.rs:19-59) in three pieces, so that the block-sorted
+// render kernel can regroup lanes between the cast and the shading:
+//   segment_cast   depth check, world.hit, hit record, emission / background  -> what happens next
+//   shade_lambert  Lambertian bounce with mixture importance sampling
+//   shade_specular Dielectric / FrostedDielectric / Metal / Isotropic
+// path_segment() chains them for the sequential users (probe kernel, tests/hostsim).
+enum : int { NEXT_LAMBERT = 0, NEXT_SPECULAR = 1, NEXT_DONE = 2 };
+
+// After the call: NEXT_DONE -> st.L is final.  Otherwise st.ray.ori is the hit point, st.ray.dir still
+// the INCOMING direction, rec.normal/u/v describe the hit and mat_index its material.
 template <class T, uint32_t F>
-__device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts) {
+__device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts, HitRecord<T>& rec,
+                                   uint32_t& mat_index) {
     if (st.seg >= max_depth) {  // depth <= 0 -> zero (:19-21); the multiply keeps NaN/inf throughput NaN
         st.L = st.L + st.beta * T(0);
-        return true;
+        return NEXT_DONE;
     }
     st.seg++;
     n_casts++;
@@ -190,27 +199,38 @@ __device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int m
     MediumXi mxi{&rng, 0.0};
     if (!world_hit<T, F>(sc, st.ray, T(0.001), Lim<T>::max(), mxi, h)) {  // :22, :59
         st.L = st.L + elemul(st.beta, V3<T>(sc.background));
-        return true;
+        return NEXT_DONE;
     }
-    const uint32_t mat_index = (has<F>(F_MEDIUM) && h.side == 7) ? sc.world[h.inst].phase_material : sc.prims[h.prim].material;
+    mat_index = (has<F>(F_MEDIUM) && h.side == 7) ? sc.world[h.inst].phase_material : sc.prims[h.prim].material;
     const DMaterial<T>& m = sc.materials[mat_index];
     const uint32_t mkind = m.kind & 0xffu;
-    HitRecord<T> rec;
     finish_hit<T, F>(sc, st.ray, h, (m.kind & 0x100u) != 0, rec);
-    const V3<T> rdir = st.ray.dir;
     st.ray.ori = rec.p;  // every scattered ray starts at the hit point and inherits ray.time (:29,34)
-    if (mkind == 0) {  // Lambertian: src/materials.rs:36-50 + ray_tracing.rs:25-43
-        V3<T> attenuation = texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p);
-        V3<T> dir; T pdf_value, scattering_pdf;
-        lambertian_sample<T, F>(sc, rec, rng, dir, pdf_value, scattering_pdf);
-        st.beta = elemul(st.beta, attenuation) * scattering_pdf / pdf_value;  // emitted == 0
-        st.ray.dir = dir;
-        return false;
-    }
+    if (mkind == 0) return NEXT_LAMBERT;
     if (mkind == 3) {  // DiffuseLight: src/materials.rs:150-159; scatter -> None -> return emitted
-        if (dot(rdir, rec.normal) < T(0)) st.L = st.L + elemul(st.beta, texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p));
-        return true;
+        if (dot(st.ray.dir, rec.normal) < T(0)) st.L = st.L + elemul(st.beta, texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p));
+        return NEXT_DONE;
     }
+    return NEXT_SPECULAR;
+}
+
+// Lambertian: src/materials.rs:36-50 + ray_tracing.rs:25-43 (emitted == 0)
+template <class T, uint32_t F>
+__device__ inline void shade_lambert(const DScene<T>& sc, PathState<T>& st, const HitRecord<T>& rec, uint32_t mat_index, Rng& rng) {
+    const DMaterial<T>& m = sc.materials[mat_index];
+    V3<T> attenuation = texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p);
+    V3<T> dir; T pdf_value, scattering_pdf;
+    lambertian_sample<T, F>(sc, rec, rng, dir, pdf_value, scattering_pdf);
+    st.beta = elemul(st.beta, attenuation) * scattering_pdf / pdf_value;
+    st.ray.dir = dir;
+}
+
+// Returns true when the path ends here (absorbed metal reflection, or a material kind outside F).
+template <class T, uint32_t F>
+__device__ inline bool shade_specular(const DScene<T>& sc, PathState<T>& st, const HitRecord<T>& rec, uint32_t mat_index, Rng& rng) {
+    const DMaterial<T>& m = sc.materials[mat_index];
+    const uint32_t mkind = m.kind & 0xffu;
+    const V3<T> rdir = st.ray.dir;
     if (has<F>(F_DIELECTRIC) && (mkind == 2 || mkind == 5)) {  // Dielectric / FrostedDielectric: src/materials.rs:81-105, 114-142
         T etai_over_etat;
         V3<T> real_normal;
@@ -246,6 +266,17 @@ __device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int m
         return false;
     }
     return true;  // unreachable for a validated scene whose feature mask is covered by F
+}
+
+// Returns true when the path has terminated (st.L is final).
+template <class T, uint32_t F>
+__device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts) {
+    HitRecord<T> rec;
+    uint32_t mat_index = 0;
+    const int next = segment_cast<T, F>(sc, st, max_depth, rng, n_casts, rec, mat_index);
+    if (next == NEXT_DONE) return true;
+    if (next == NEXT_LAMBERT) { shade_lambert<T, F>(sc, st, rec, mat_index, rng); return false; }
+    return shade_specular<T, F>(sc, st, rec, mat_index, rng);
 }
 
 // Fresh camera path for sample (u,v): src/ray_tracing.rs:103

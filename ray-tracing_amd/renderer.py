@@ -100,12 +100,12 @@ class DeviceScene:
         return ids, ts
 
     def render_into(self, accum, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
-                    max_nan_retries=64):
+                    max_nan_retries=64, no_sort=False):
         """accum: float32 CUDA tensor [H, W, 3] (row = y upward), ADDED to. stats: uint64-as-int64 tensor [4] or None."""
         assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.dim() == 3 and accum.shape[2] == 3
         h, w = accum.shape[0], accum.shape[1]
         p = RtRenderParams(w, h, int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
-                           _PRECISION[precision], 0)
+                           _PRECISION[precision], 1 if no_sort else 0)
         sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
         with torch.cuda.device(self.device):
             check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), sp, self._stream()))
