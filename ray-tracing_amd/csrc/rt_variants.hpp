@@ -18,6 +18,15 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
     return sizeof(T) == 8 ? (((F & F_BVH) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
 #endif
 }
+// The block-sorted kernel waits at two barriers per iteration: it wants more resident waves than the wave-level
+// kernel even at the price of a few spills (f64 Cornell: +14 % at 4 waves/SIMD vs 3; its 39.5 KB of LDS admit 4 blocks).
+template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
+#ifdef RT_WAVES_PER_SIMD_SORTED
+    return RT_WAVES_PER_SIMD_SORTED;
+#else
+    return 4;
+#endif
+}
 // LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
 // register budget does: f64 2 blocks x (64 KB + 6 KB tile sums), f32 3 blocks x (44 KB + 6 KB) of 160 KB.
 template <class T> __device__ __host__ constexpr uint32_t lds_bvh_entries() {

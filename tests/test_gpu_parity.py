@@ -218,3 +218,24 @@ def test_f32_render_statistics(scenes):
         ma, mb = a.mean((0, 1)).cpu().numpy(), b.mean((0, 1)).cpu().numpy()
         assert np.allclose(ma, mb, rtol=0.05), (name, ma, mb)
         assert st[0].item() == 64 * 64 * 256 and st[3].item() == 0
+
+
+@pytest.mark.parametrize("name", ("cornell_box", "cornell_smoke", "simple_light", "two_checker_spheres"))
+def test_wave_kernel_and_sorted_kernel_agree(name, scenes):
+    # scenes without BVH instances run the block-sorted kernel by default; RT_RENDER_NO_SORT selects the
+    # wave-level kernel.  Same keyed samples -> same sums (up to the order of the f64 additions per pixel),
+    # and both equal the oracle's frame.
+    W, H, spp = 50, 35, 5  # ragged against the 16x16 tiles
+    ds = scenes(name)
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    b = torch.zeros_like(a)
+    sa = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    sb = torch.zeros_like(sa)
+    ds.render_into(a, 2, spp, precision="f64", stats=sa)
+    ds.render_into(b, 2, spp, precision="f64", stats=sb, no_sort=True)
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert sa.tolist() == sb.tolist() and sa[0].item() == W * H * spp
+    ref, cnt = OracleScene(name, 1.0).render(W, H, 2, spp, threads=8)
+    close = (np.abs(a.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+    assert close.mean() >= 0.998
+    assert abs(int(sa[1]) - cnt["casts"]) <= 0.002 * cnt["casts"]
