@@ -22,6 +22,14 @@
 #endif
 #include <stdint.h>
 
+// tests/hostsim can count traversal events (node classifications, exact fallbacks, leaf tests); a no-op on the device
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+extern "C" unsigned long long g_sim_counters[8];
+#define RT_SIM_COUNT(i) (g_sim_counters[i]++)
+#else
+#define RT_SIM_COUNT(i) ((void)0)
+#endif
+
 namespace rt {
 
 // ------------------------------------------------------------------------------------------
@@ -78,6 +86,7 @@ template <class T> struct DScene {
     const DBvhLite* bvh_lite;       // same indexing as bvh
     const DBvhLite* bvh_lds;        // entries [0, n_bvh_lds) of bvh_lite staged in LDS by the render kernel (else n_bvh_lds = 0)
     uint32_t n_bvh, n_bvh_lds;
+    T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
     uint32_t n_world, n_lights;
     T background[3];
     DCamera<T> cam;
@@ -368,34 +377,64 @@ template <class T> __device__ inline bool aabb_hit(const T* mn, const T* mx, V3<
     return ok;
 }
 
-// Cheap classification of a node against the ray, in f32 and WITHOUT divisions: 1 = the reference's
-// loose test certainly passes, 0 = no primitive below this node can be hit inside (t_min, t_max)
-// (cull), 2 = too close to call -> the caller evaluates aabb_hit exactly (in T, true divisions).
-//   Inputs: the node's box rounded outward to f32, the ray origin and reciprocal direction rounded
-//   to f32.  a = (bound - o) * (1/d) then differs from the reference's (bound - o) / d by a relative
-//   error < 5e-7 of (|o| + |bound|)|1/d|.  With gap = min(t_max, hi_xyz) - max(t_min, lo_xyz) (the
-//   proper slab intersection) and tol = 2^-16 (|o| + B)|1/d|  (B = largest |coordinate| of the tree):
-//   gap >  tol: every axis overlaps (t_min,t_max) by more than all rounding -> the per-axis loose
-//               test on the exact box passes, exactly as in the reference -> descend;
-//   gap < -tol: a hit at t in (t_min,t_max) below this node would lie inside the node's box, i.e.
-//               inside every slab interval up to the hit point's rounding error (~1e-13 in f64),
-//               which tol exceeds by orders of magnitude -> skipping the subtree cannot change the
-//               closest hit, whatever the loose test says;
+// Cheap classification of a box against the ray, in f32 and WITHOUT divisions: 1 = the reference's
+// loose test certainly passes, 0 = nothing inside this box can be hit in (t_min, t_max) (cull),
+// 2 = too close to call -> the caller evaluates aabb_hit exactly (in T, true divisions).
+//   Inputs: the box rounded outward to f32, the ray origin and reciprocal direction rounded to f32.
+//   a = (bound - o) * (1/d) then differs from the reference's (bound - o) / d by less than
+//   e_i = 2^-18 (|o_i| + B) |1/d_i|  per axis (B = largest |coordinate| of the tree; the true error
+//   is < 5e-7 of that scale, e_i is 7x larger).  Each slab interval [lo_i, hi_i] is therefore known
+//   to within e_i, and (t_min, t_max) to within their f32 rounding:
+//   inner = min(t_max-, hi_i - e_i) - max(t_min+, lo_i + e_i) > 0: every axis overlaps (t_min,t_max)
+//           by more than all rounding -> the per-axis loose test on the exact box passes, exactly
+//           as in the reference -> descend;
+//   outer = min(t_max+, hi_i + e_i) - max(t_min-, lo_i - e_i) < 0: a hit at t in (t_min,t_max)
+//           inside this box would lie inside every slab interval up to the hit point's rounding
+//           error (~1e-13 in f64), which e_i exceeds by orders of magnitude -> skipping cannot
+//           change the closest hit, whatever the loose test says;
 //   otherwise (grazing rays, axis-parallel rays with 1/d = inf, NaN, f32 overflow): the exact test.
 // The reference's loose test lets through ~27 % of a 480-node tree per ray; the cull visits the few
 // nodes the ray actually crosses and still returns the identical hit (ids and t bit-exact).
-__device__ inline int aabb_classify(const DBvhLite& e, float ox, float oy, float oz, float ix, float iy, float iz, float t_min,
-                                    float t_max, float tol) {
-    const float x1 = (e.mn[0] - ox) * ix, x2 = (e.mx[0] - ox) * ix;
-    const float y1 = (e.mn[1] - oy) * iy, y2 = (e.mx[1] - oy) * iy;
-    const float z1 = (e.mn[2] - oz) * iz, z2 = (e.mx[2] - oz) * iz;
-    const float lx = x1 < x2 ? x1 : x2, hx = x1 < x2 ? x2 : x1;
-    const float ly = y1 < y2 ? y1 : y2, hy = y1 < y2 ? y2 : y1;
-    const float lz = z1 < z2 ? z1 : z2, hz = z1 < z2 ? z2 : z1;
-    float enter = lx > ly ? lx : ly; enter = enter > lz ? enter : lz; enter = enter > t_min ? enter : t_min;
-    float exit = hx < hy ? hx : hy; exit = exit < hz ? exit : hz; exit = exit < t_max ? exit : t_max;
-    const float gap = exit - enter;
-    return gap > tol ? 1 : (gap < -tol ? 0 : 2);
+// R = float on the f32 box: first level (cheap).  R = double on the EXACT f64 box (f64 mode only): second level
+// for the lanes the first could not decide; its only error is f64 rounding (e_i = 2^-46 (|o_i| + B)|1/d_i|), so it
+// resolves e.g. rays that START on a box face (t_min = 0.001 is below the f32 resolution at coordinates ~1000)
+// without the 6-division exact test, which is left with genuine ties (a hit lying on a plane two boxes share).
+template <class R> struct RayR { R ox, oy, oz, ix, iy, iz, ex, ey, ez, tmin_lo, tmin_hi; };
+__device__ inline float rminf(float a, float b) { return fminf(a, b); }
+__device__ inline float rmaxf(float a, float b) { return fmaxf(a, b); }
+__device__ inline double rminf(double a, double b) { return ::fmin(a, b); }
+__device__ inline double rmaxf(double a, double b) { return ::fmax(a, b); }
+template <class R, class BoxT>
+__device__ inline int aabb_classify(const BoxT* mn, const BoxT* mx, const RayR<R>& r, R tmax_lo, R tmax_hi) {
+    const R x1 = ((R)mn[0] - r.ox) * r.ix, x2 = ((R)mx[0] - r.ox) * r.ix;
+    const R y1 = ((R)mn[1] - r.oy) * r.iy, y2 = ((R)mx[1] - r.oy) * r.iy;
+    const R z1 = ((R)mn[2] - r.oz) * r.iz, z2 = ((R)mx[2] - r.oz) * r.iz;
+    const R lx = x1 < x2 ? x1 : x2, hx = x1 < x2 ? x2 : x1;
+    const R ly = y1 < y2 ? y1 : y2, hy = y1 < y2 ? y2 : y1;
+    const R lz = z1 < z2 ? z1 : z2, hz = z1 < z2 ? z2 : z1;
+    const R in_lo = rmaxf(rmaxf(lx + r.ex, ly + r.ey), rmaxf(lz + r.ez, r.tmin_hi));
+    const R in_hi = rminf(rminf(hx - r.ex, hy - r.ey), rminf(hz - r.ez, tmax_lo));
+    const R out_lo = rmaxf(rmaxf(lx - r.ex, ly - r.ey), rmaxf(lz - r.ez, r.tmin_lo));
+    const R out_hi = rminf(rminf(hx + r.ex, hy + r.ey), rminf(hz + r.ez, tmax_hi));
+    // NaN anywhere (0 * inf on an axis-parallel ray, ...) -> undecided
+    const bool nan = (lx != lx) | (ly != ly) | (lz != lz) | (hx != hx) | (hy != hy) | (hz != hz) | (r.ex != r.ex) | (r.ey != r.ey) | (r.ez != r.ez);
+    if (nan) return 2;
+    return in_hi - in_lo > R(0) ? 1 : (out_hi - out_lo < R(0) ? 0 : 2);
+}
+// t widened by one part in 2^20 either way (covers its rounding to f32; harmless in f64)
+template <class R> __device__ inline void widen(R t, R& lo, R& hi) {
+    const R w = (t < R(0) ? -t : t) * R(9.5367431640625e-07);
+    lo = t - w; hi = t + w;
+}
+template <class R, class T>
+__device__ inline void ray_consts(RayR<R>& r, V3<T> o, V3<T> d, T t_min, R B, R rel) {
+    r.ox = (R)o.x; r.oy = (R)o.y; r.oz = (R)o.z;
+    r.ix = R(1) / (R)d.x; r.iy = R(1) / (R)d.y; r.iz = R(1) / (R)d.z;
+    const R tiny = R(1e-30);
+    r.ex = ((r.ox < 0 ? -r.ox : r.ox) + B + tiny) * rel * (r.ix < 0 ? -r.ix : r.ix);
+    r.ey = ((r.oy < 0 ? -r.oy : r.oy) + B + tiny) * rel * (r.iy < 0 ? -r.iy : r.iy);
+    r.ez = ((r.oz < 0 ? -r.oz : r.oz) + B + tiny) * rel * (r.iz < 0 ? -r.iz : r.iz);
+    widen<R>((R)t_min, r.tmin_lo, r.tmin_hi);
 }
 
 // Entry i of the table staged in LDS.  The generic pointer is narrowed to the LDS address space by hand
@@ -434,36 +473,49 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
     T closest = t_max;
     int i = sc.bvh_root_entry[geom_index];
     const int n_lds = (int)sc.n_bvh_lds;
-    // per-ray constants of the node classification
-    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
-    const float tminf = (float)t_min;
-    float tol;
+    // per-ray constants of the box classification
     int end;
+    float B;
     {
         const DBvhLite& root = sc.bvh_lite[i];
         end = root.skip;
-        float B = fabsf(root.mn[0]);
+        B = fabsf(root.mn[0]);
         B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
         B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
-        const float rel = 1.52587890625e-05f, tiny = 1e-30f;  // 2^-16
-        const float px = (fabsf(ox) + B + tiny) * rel * fabsf(ix);
-        const float py = (fabsf(oy) + B + tiny) * rel * fabsf(iy);
-        const float pz = (fabsf(oz) + B + tiny) * rel * fabsf(iz);
-        tol = px > py ? px : py; tol = tol > pz ? tol : pz;
-        if (!(tol == tol)) tol = 3.402823466e+38f;  // NaN -> nothing is certain -> exact tests
     }
+    RayR<float> r;
+    ray_consts<float, T>(r, o, d, t_min, B, 3.814697265625e-06f);  // 2^-18 (|o| + B): f32 rounding of o, box, products
+    RayR<T> r2;                                                    // second level, used in f64 mode only
+    if (sizeof(T) == 8) {
+        ray_consts<T, T>(r2, o, d, t_min, (T)B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
+    }
+    // leaves carry their primitive's own box: most leaf visits are misses (measured 94 % in random_scene) and
+    // an exact sphere / cuboid test costs 70-270 f64 instructions.  Moving spheres' boxes cover sc.time_lo..time_hi.
+    const bool leaf_cull = time >= sc.time_lo && time <= sc.time_hi;
     for (;;) {
         int prim = -1;
-        float closestf = (float)closest;
+        float tmax_lo, tmax_hi;
+        widen<float>((float)closest, tmax_lo, tmax_hi);
         while (i != end) {
             DBvhLite e;
             if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
             prim = e.prim;
-            if (prim >= 0) break;
-            const int c = aabb_classify(e, ox, oy, oz, ix, iy, iz, tminf, closestf, tol);
+            int c = aabb_classify<float, float>(e.mn, e.mx, r, tmax_lo, tmax_hi);
+            RT_SIM_COUNT(0);
+            if (sizeof(T) == 8 && c == 2 && prim < 0) {  // second level: f64 ray against the exact box
+                RT_SIM_COUNT(5);
+                const DBvhEntry<T>& ex = sc.bvh[i];
+                c = aabb_classify<T, T>(ex.mn, ex.mx, r2, closest, closest);
+            }
+            if (prim >= 0) {
+                if (c != 0 || !leaf_cull) break;  // test this leaf
+                RT_SIM_COUNT(4);
+                i = i + 1;                         // certainly missed: next entry
+                continue;
+            }
             bool pass = c == 1;
             if (c == 2) {  // rare: the reference's exact decision on the exact box
+                RT_SIM_COUNT(1);
                 const DBvhEntry<T>& ex = sc.bvh[i];
                 pass = aabb_hit(ex.mn, ex.mx, o, d, t_min, closest);
             }
@@ -471,7 +523,9 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
         }
         if (i == end) break;
         T t; int side;
+        RT_SIM_COUNT(2);
         if (prim_hit<T, F>(sc.prims[prim], o, d, time, t_min, closest, t, side)) {
+            RT_SIM_COUNT(3);
             any = true; closest = t; prim_out = prim; side_out = side;
         }
         i = i + 1;
@@ -541,6 +595,18 @@ template <class T, uint32_t F>
 __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min, T t_max, MediumXi& mxi, Hit<T>& hit) {
     bool any = false;
     T closest = t_max;
+    // A ray with a NaN in its origin or direction (a bounce whose pdf was 0/0; the sample will be retried,
+    // ray_tracing.rs:107) hits nothing: every primitive test compares a NaN and fails, and no medium draws.
+    // In the reference it still walks every BVH completely, because a NaN slab passes the loose box test
+    // (f64::min/max ignore NaN).  Same result, none of the work:
+    {
+        const T chk = ray.ori.x + ray.ori.y + ray.ori.z + ray.dir.x + ray.dir.y + ray.dir.z;
+        if (chk != chk) {
+            const bool nan = (ray.ori.x != ray.ori.x) | (ray.ori.y != ray.ori.y) | (ray.ori.z != ray.ori.z) |
+                             (ray.dir.x != ray.dir.x) | (ray.dir.y != ray.dir.y) | (ray.dir.z != ray.dir.z);
+            if (nan) return false;  // (chk is also NaN for inf - inf: those rays take the normal route)
+        }
+    }
     for (uint32_t i = 0; i < sc.n_world; i++) {
         const DInstance<T>& in = sc.world[i];
         V3<T> o = ray.ori, d = ray.dir;

@@ -274,16 +274,54 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     };
     add_roots(d->world, d->n_world);
     add_roots(d->lights, d->n_lights);
-    // f32 copies of the boxes, rounded outward so that they contain the exact boxes
-    auto down = [](T x) { float f = (float)x; return ((T)f > x) ? std::nextafterf(f, -INFINITY) : f; };
-    auto up = [](T x) { float f = (float)x; return ((T)f < x) ? std::nextafterf(f, INFINITY) : f; };
+    // f32 copies of the boxes, rounded outward so that they contain the exact boxes; a leaf gets the box of its
+    // primitive (computed from the f64 description; moving spheres over the time hull below)
+    const double time_lo = std::fmin(0.0, d->camera.t1), time_hi = std::fmax(1.0, d->camera.t2);
+    auto down = [](double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; };
+    auto up = [](double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; };
     for (const DBvhEntry<T>& e : h.bvh) {
         DBvhLite l;
-        for (int k = 0; k < 3; k++) { l.mn[k] = down(e.mn[k]); l.mx[k] = up(e.mx[k]); }
+        double mn[3], mx[3];
+        if (e.prim < 0) {
+            for (int k = 0; k < 3; k++) { mn[k] = (double)e.mn[k]; mx[k] = (double)e.mx[k]; }
+        } else {
+            const RtPrim& p = d->prims[e.prim];
+            const double big = 1e300;
+            switch (p.kind) {
+                case RT_PRIM_SPHERE: {
+                    double r = std::fabs(p.d[3]);
+                    for (int k = 0; k < 3; k++) { mn[k] = p.d[k] - r; mx[k] = p.d[k] + r; }
+                    break;
+                }
+                case RT_PRIM_MOVING_SPHERE: {
+                    double r = std::fabs(p.d[8]), den = p.d[7] - p.d[6];
+                    for (int k = 0; k < 3; k++) {
+                        double c0 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_lo - p.d[6]) / den);
+                        double c1 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_hi - p.d[6]) / den);
+                        double pad = 1e-9 * (std::fabs(c0) + std::fabs(c1) + r + 1.0);  // centre arithmetic rounding
+                        mn[k] = std::fmin(c0, c1) - r - pad; mx[k] = std::fmax(c0, c1) + r + pad;
+                        if (!(mn[k] == mn[k]) || !(mx[k] == mx[k])) { mn[k] = -big; mx[k] = big; }
+                    }
+                    break;
+                }
+                case RT_PRIM_CUBOID:
+                    for (int k = 0; k < 3; k++) { mn[k] = std::fmin(p.d[k], p.d[3 + k]); mx[k] = std::fmax(p.d[k], p.d[3 + k]); }
+                    break;
+                default: {  // rects: a1,a2,b1,b2,k  (objects.rs:245-250 pads the thin axis by 1e-4; so do we)
+                    int axis = (int)p.kind - RT_PRIM_RECT_XY;  // 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x)
+                    int ia = axis == 2 ? 1 : 0, ib = axis == 0 ? 1 : 2, ik = 2 - axis;
+                    mn[ia] = std::fmin(p.d[0], p.d[1]); mx[ia] = std::fmax(p.d[0], p.d[1]);
+                    mn[ib] = std::fmin(p.d[2], p.d[3]); mx[ib] = std::fmax(p.d[2], p.d[3]);
+                    mn[ik] = p.d[4] - 0.0001; mx[ik] = p.d[4] + 0.0001;
+                }
+            }
+        }
+        for (int k = 0; k < 3; k++) { l.mn[k] = down(mn[k]); l.mx[k] = up(mx[k]); }
         l.skip = e.skip; l.prim = e.prim;
         h.bvh_lite.push_back(l);
     }
     DScene<T>& out = h.view;
+    out.time_lo = (T)time_lo; out.time_hi = (T)time_hi;
     out.n_bvh = (uint32_t)h.bvh.size();
     out.n_bvh_lds = 0;
     out.bvh_lds = nullptr;

@@ -14,9 +14,9 @@ BENCH_SHORT="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32 ${BENCH_AR
 fatal() { case $1 in 124|137|134|139|-6|-11) echo "step '$2' ended with $1: stopping" | tee -a "$OUT/status.txt"; exit "$1";; esac; }
 step() {  # step <name> <seconds> <cmd...>
   local name=$1 secs=$2; shift 2
-  echo "== $name" | tee -a "$OUT/status.txt"
+  echo "== $name" | tee -a "$OUT/status.txt" >&2
   timeout -k 10 "$secs" "$@"; local rc=$?
-  echo "$name rc=$rc" | tee -a "$OUT/status.txt"
+  echo "$name rc=$rc" | tee -a "$OUT/status.txt" >&2
   fatal $rc "$name"
   return $rc
 }
