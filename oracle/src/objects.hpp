@@ -432,6 +432,11 @@ struct RotateY : Object {
         double radians = angle * PI / 180.0;
         sin_theta = std::sin(radians);
         cos_theta = std::cos(radians);
+        init_box();
+    }
+    // oracle addition: rebuild from a flattened scene, where sin/cos are stored (transforms.rs:44-45 fields)
+    RotateY(ObjPtr o, double sin_t, double cos_t, int /*from_sincos*/) : object(std::move(o)), sin_theta(sin_t), cos_theta(cos_t) { init_box(); }
+    void init_box() {  // transforms.rs:53-87
         Aabb bb;
         has_box = object->bounding_box(0.0, 1.0, bb);
         if (has_box) {

@@ -491,7 +491,11 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
     }
     // leaves carry their primitive's own box: most leaf visits are misses (measured 94 % in random_scene) and
     // an exact sphere / cuboid test costs 70-270 f64 instructions.  Moving spheres' boxes cover sc.time_lo..time_hi.
+#ifdef RT_DBG_NO_LEAF_CULL
+    const bool leaf_cull = false;
+#else
     const bool leaf_cull = time >= sc.time_lo && time <= sc.time_hi;
+#endif
     for (;;) {
         int prim = -1;
         float tmax_lo, tmax_hi;

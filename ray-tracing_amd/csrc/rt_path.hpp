@@ -208,7 +208,10 @@ __device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int ma
     st.ray.ori = rec.p;  // every scattered ray starts at the hit point and inherits ray.time (:29,34)
     if (mkind == 0) return NEXT_LAMBERT;
     if (mkind == 3) {  // DiffuseLight: src/materials.rs:150-159; scatter -> None -> return emitted
+        // the unlit side returns Vec3::zero(): the recursion multiplies it by every bounce's weight on the way up,
+        // so a NaN / inf throughput still turns the sample NaN (and it is retried) — keep that with beta * 0
         if (dot(st.ray.dir, rec.normal) < T(0)) st.L = st.L + elemul(st.beta, texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p));
+        else st.L = st.L + st.beta * T(0);
         return NEXT_DONE;
     }
     return NEXT_SPECULAR;
@@ -257,7 +260,8 @@ __device__ inline bool shade_specular(const DScene<T>& sc, PathState<T>& st, con
             st.ray.dir = dir;
             return false;
         }
-        return true;  // absorbed: returns emitted == 0
+        st.L = st.L + st.beta * T(0);  // absorbed: returns emitted == 0, weighted by the bounces above (NaN stays NaN)
+        return true;
     }
     if (has<F>(F_MEDIUM) && mkind == 4) {  // Isotropic: src/materials.rs:167-172
         V3<T> attenuation = texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p);

@@ -70,6 +70,25 @@ class HostScene:
             pass
 
 
+class FlatHostScene:
+    """A flat scene built in Python (flat.FlatScene / flat.scene_from_json) with HostScene's interface."""
+
+    def __init__(self, flat_scene, name="flat"):
+        self.name, self.flat = name, flat_scene
+        self._desc = flat_scene.desc()
+
+    @property
+    def desc(self):
+        return self._desc
+
+    @property
+    def desc_ptr(self):
+        return C.cast(C.pointer(self._desc), C.c_void_p)
+
+    def close(self):
+        pass
+
+
 class DeviceScene:
     """rt_scene_create on the current device."""
 

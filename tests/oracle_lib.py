@@ -33,6 +33,8 @@ def lib():
         L.orc_resolve.argtypes = [vp, u32, u32, u32, vp]
         L.orc_bvh_dump.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.orc_bvh_dump.restype = C.c_int
+        L.orc_scene_from_desc.argtypes, L.orc_scene_from_desc.restype = [vp], vp
+        L.orc_from_desc_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -47,6 +49,16 @@ class OracleScene:
         if not self._h:
             raise RuntimeError(lib().orc_last_error().decode())
         self.name = name
+
+    @classmethod
+    def from_desc(cls, desc_ptr, name="flat"):
+        """Oracle scene graph rebuilt from a flattened description (oracle/src/from_desc.cpp)."""
+        self = cls.__new__(cls)
+        self._h = lib().orc_scene_from_desc(desc_ptr)
+        if not self._h:
+            raise RuntimeError(lib().orc_from_desc_error().decode())
+        self.name = name
+        return self
 
     def close(self):
         if self._h:

@@ -1,0 +1,86 @@
+"""Scenes that do not come from the nine named constructors: the oracle rebuilt from ANY flattened description
+(oracle/src/from_desc.cpp), randomly generated flat scenes, and the reference's JSON scene data
+(codegen/data/scene_10.json through flat.scene_from_json).  CPU: the device templates (tests/hostsim) against
+the oracle.  The GPU versions of the same comparisons are in tests/test_gpu_parity.py."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from ray_tracing_amd import flat
+from oracle_lib import OracleScene
+from flat_fuzz import random_scene
+from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
+
+REF_JSON = "/root/reference/codegen/data/scene_10.json"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", rt.SCENES)
+def test_oracle_from_desc_equals_named_scene(name, golden_dir):
+    # flatten -> rebuild in the oracle's object model -> same ids, t and radiance as the directly constructed scene:
+    # the flat form loses nothing the path depends on
+    hs = rt.HostScene(name, 1.0)
+    oc = OracleScene.from_desc(hs.desc_ptr)
+    g = np.load(os.path.join(golden_dir, f"primary_{name}.npz"))
+    ids, ts = oc.trace_primary(64, 64, 0.5, float(g["medium_xi"]))
+    assert np.array_equal(ids, g["ids_t05"]) and np.array_equal(ts, g["t_t05"])
+    s = oc.sample_pixel(48, 48, 20, 13, 0, 16)
+    assert np.array_equal(s, np.load(os.path.join(golden_dir, f"samples_{name}.npz"))["rgb"][:16])
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_flat_scene_sim_equals_oracle(sim, seed):
+    fs = random_scene(seed)
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    W, H = 40, 30
+    for tm, xi in ((0.0, 0.5), (0.6, 0.05)):
+        for generic in (False, True):
+            ids, ts = sc.primary(W, H, tm, xi, "f64", generic)
+            oi, ot = oc.trace_primary(W, H, tm, xi)
+            assert np.array_equal(ids, oi), (seed, tm, generic, int((ids != oi).sum()))
+            assert np.array_equal(ts, ot)
+    got, casts = sc.render(20, 15, 0, 4)
+    ref, cnt = oc.render(20, 15, 0, 4, threads=4)
+    assert casts == cnt["casts"], (seed, casts, cnt["casts"])
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True), (seed, np.nanmax(np.abs(got - ref)))
+
+
+def test_flat_scene_dict_roundtrip():
+    fs = random_scene(3)
+    fs2 = flat.FlatScene.from_dict(json.loads(json.dumps(fs.to_dict())))
+    a, b = fs.desc(), fs2.desc()
+    assert a.n_prims == b.n_prims and a.n_world == b.n_world and a.bvh.n_nodes == b.bvh.n_nodes
+    for i in range(a.n_prims):
+        assert list(a.prims[i].d) == list(b.prims[i].d) and a.prims[i].kind == b.prims[i].kind
+    assert list(a.camera.horizontal) == list(b.camera.horizontal)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_JSON), reason="reference JSON scene data not present")
+def test_reference_json_scene_loads_and_matches_fixture(sim):
+    # codegen/data/scene_10.json: 25 spheres, 19 BVHNode records with an explicit topology.  The committed fixture
+    # (tools/make_json_fixture.py) holds the flat form derived from it and the oracle's probe of it.
+    fs = flat.scene_from_json(open(REF_JSON).read())
+    d = fs.desc()
+    assert d.n_prims == 25 and d.bvh.n_nodes == 19 and d.n_world == 6 and d.n_lights == 0
+    fx = np.load(os.path.join(GOLDEN, "json_scene10.npz"))
+    assert json.loads(str(fx["flat_scene"])) == json.loads(json.dumps(fs.to_dict()))
+
+
+def test_json_fixture_sim_equals_oracle(sim):
+    fx = np.load(os.path.join(GOLDEN, "json_scene10.npz"))
+    fs = flat.FlatScene.from_dict(json.loads(str(fx["flat_scene"])))
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ids, ts = oc.trace_primary(64, 64, 0.0, 0.5)
+    assert np.array_equal(ids, fx["ids"]) and np.array_equal(ts, fx["t"])           # oracle vs its committed output
+    sc = SimScene.from_host(sim, host)
+    ids2, ts2 = sc.primary(64, 64, 0.0, 0.5)
+    assert np.array_equal(ids2, fx["ids"]) and np.array_equal(ts2, fx["t"])         # device templates, bit-exact
+    got, _ = sc.samples(32, 32, 0, 11, 0, 32)
+    assert np.allclose(got, fx["samples"], rtol=RAD_RTOL, atol=0)

@@ -239,3 +239,49 @@ def test_wave_kernel_and_sorted_kernel_agree(name, scenes):
     close = (np.abs(a.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
     assert close.mean() >= 0.998
     assert abs(int(sa[1]) - cnt["casts"]) <= 0.002 * cnt["casts"]
+
+
+# ---- scenes outside the nine named constructors ----------------------------------------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_random_flat_scene_gpu_equals_oracle(seed, gpu):
+    # randomly generated flat scenes (tests/flat_fuzz.py): every primitive / material / texture kind, transform
+    # chains, BVHs, media, light lists — HIP path vs the oracle rebuilt from the same description
+    from flat_fuzz import random_scene
+    host = rt.FlatHostScene(random_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        W, H = 48, 36
+        for tm, xi in ((0.0, 0.5), (0.6, 0.05)):
+            ids, ts = ds.trace_primary(W, H, tm, xi, "f64")
+            oi, ot = oc.trace_primary(W, H, tm, xi)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot)
+        spp = 4
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        for no_sort in (False, True):
+            acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+            st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            ds.render_into(acc, 0, spp, precision="f64", stats=st, no_sort=no_sort)
+            got = acc.cpu().numpy().astype(np.float64)
+            close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+            assert close.mean() >= 0.995, (seed, no_sort, close.mean())
+            assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
+
+
+def test_json_scene_fixture_gpu(gpu, golden_dir):
+    # the reference's codegen/data/scene_10.json in flat form (tests/golden/json_scene10.npz, tools/make_json_fixture.py)
+    import json
+    from ray_tracing_amd import flat
+    fx = np.load(os.path.join(golden_dir, "json_scene10.npz"))
+    host = rt.FlatHostScene(flat.FlatScene.from_dict(json.loads(str(fx["flat_scene"]))))
+    ds = rt.DeviceScene(host, 0)
+    try:
+        ids, ts = ds.trace_primary(64, 64, 0.0, 0.5, "f64")
+        assert np.array_equal(ids.cpu().numpy(), fx["ids"]) and np.array_equal(ts.cpu().numpy(), fx["t"])
+        got = ds.sample_pixel(32, 32, 0, 11, 0, 32, precision="f64").cpu().numpy()
+        ref = fx["samples"]
+        assert (np.abs(got - ref) <= SAMPLE_RTOL * np.maximum(np.abs(ref), 1.0)).all(axis=1).sum() >= 31
+    finally:
+        ds.close()

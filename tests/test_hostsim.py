@@ -61,6 +61,15 @@ class SimScene:
         self.h = L.sim_scene_create(self.host.desc_ptr, C.byref(rc))
         assert self.h, L.sim_last_error()
 
+    @classmethod
+    def from_host(cls, L, host):
+        self = cls.__new__(cls)
+        self.L, self.host = L, host
+        rc = C.c_int()
+        self.h = L.sim_scene_create(host.desc_ptr, C.byref(rc))
+        assert self.h, L.sim_last_error()
+        return self
+
     def primary(self, W, H, time, xi, precision="f64", generic=False):
         ids = np.zeros((H, W), dtype=np.int32)
         ts = np.zeros((H, W))
