@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra f32 throughput measurement")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = sized to ~15 s)")
+    ap.add_argument("--no-sort", action="store_true", help="run the wave-level kernel where the block-sorted one would be used")
     ap.add_argument("--out-png", default="")
     return ap.parse_args()
 
@@ -145,7 +146,7 @@ def main():
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ds.render_into(accum, step_range(i), S, seed=a.seed, precision=precision, stats=stats)
+            ds.render_into(accum, step_range(i), S, seed=a.seed, precision=precision, stats=stats, no_sort=a.no_sort)
             if events is not None:
                 e1.record()
                 events.append((e0, e1))

@@ -41,8 +41,8 @@ def _run(cmd):
         raise RuntimeError("build failed: " + " ".join(cmd))
 
 
-def build_hip(force=False, defines=(), out=None, tag=""):
-    """defines/out/tag: build an A/B variant library (tools/gpu_ab.py) beside the product one."""
+def build_hip(force=False, defines=(), out=None, tag="", f64_flags=()):
+    """defines/out/tag/f64_flags: build an A/B variant library (tools/build_ab.py) beside the product one."""
     global LIB_HIP
     lib_out = out or LIB_HIP
     os.makedirs(OBJ, exist_ok=True)
@@ -53,7 +53,8 @@ def build_hip(force=False, defines=(), out=None, tag=""):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", tag + ".o"))
         if force or _newer(o, [s] + headers):
-            _run([HIPCC] + COMMON + flags + ["-D" + d for d in defines] + ["-c", s, "-o", o])
+            extra = list(f64_flags) if src == "rt_kernels_f64.hip" else []
+            _run([HIPCC] + COMMON + flags + extra + ["-D" + d for d in defines] + ["-c", s, "-o", o])
         objs.append(o)
     if force or _newer(lib_out, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_out] + objs)

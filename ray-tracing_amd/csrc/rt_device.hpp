@@ -49,6 +49,7 @@ enum : uint32_t {
     F_LIGHTS = 1u << 10,     // lights = Some(..): mixture importance sampling
     F_TEXTURED = 1u << 11,   // any non-SolidColor texture (checker / noise / image)
     F_UV = 1u << 12,         // some material needs the hit's (u,v)
+    F_NOISE = 1u << 13,      // a NoiseTexture exists: the render kernels stage Perlin tables in LDS
     F_ALL = 0xffffffffu
 };
 template <uint32_t F> __device__ constexpr bool has(uint32_t bit) { return (F & bit) != 0; }
@@ -59,7 +60,13 @@ template <uint32_t F> __device__ constexpr bool has(uint32_t bit) { return (F & 
 template <class T> struct DPrim { T d[10]; uint32_t kind, material; };
 template <class T> struct DMaterial { T albedo[3]; T fuzz, ref_idx; uint32_t kind, texture; };
 template <class T> struct DTexture { T color[3]; T scale; uint32_t kind, odd, even, table; };
-template <class T> struct DPerlin { T ranvec[256][3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; };
+// Perlin table (texture.rs:100-105).  The render kernels stage copies in LDS: f32 vectors are padded to 4
+// components (one ds_read_b128 per vector); f64 vectors are not (two tables + the sort buffers must fit 3 blocks per CU)
+template <class T> struct alignas(16) DPerlin {
+    static constexpr uint32_t kStride = sizeof(T) == 4 ? 4u : 3u;
+    T ranvec[256][kStride];
+    uint8_t perm[3][256];
+};
 struct DImage { const uint8_t* rgb; uint32_t width, height; };
 template <class T> struct DXform { T v[3]; uint32_t kind; };
 template <class T> struct DInstance { T density; uint32_t geom_kind, geom_index, xform_begin, xform_count, is_medium, phase_material; };
@@ -86,6 +93,8 @@ template <class T> struct DScene {
     const DBvhLite* bvh_lite;       // same indexing as bvh
     const DBvhLite* bvh_lds;        // entries [0, n_bvh_lds) of bvh_lite staged in LDS by the render kernel (else n_bvh_lds = 0)
     uint32_t n_bvh, n_bvh_lds;
+    const DPerlin<T>* perlin_lds;     // perlins [0, n_perlin_lds) staged in LDS by the render kernel (else n_perlin_lds = 0)
+    uint32_t n_perlins, n_perlin_lds;
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
     uint32_t n_world, n_lights;
     T background[3];
@@ -719,14 +728,51 @@ __device__ inline int32_t as_i32(float x) { return x != x ? 0 : (x >= 2147483648
 __device__ inline uint32_t as_u32(double x) { return x != x ? 0u : (x >= 4294967295.0 ? 4294967295u : (x <= 0.0 ? 0u : (uint32_t)x)); }
 __device__ inline uint32_t as_u32(float x) { return x != x ? 0u : (x >= 4294967296.0f ? 4294967295u : (x <= 0.0f ? 0u : (uint32_t)x)); }
 
+// Where a Perlin table is read from: the scene's global record, or the render kernel's LDS copy.
+template <class T> struct PerlinGlobal {
+    const DPerlin<T>* p;
+    __device__ uint32_t px(uint32_t i) const { return p->perm[0][i]; }
+    __device__ uint32_t py(uint32_t i) const { return p->perm[1][i]; }
+    __device__ uint32_t pz(uint32_t i) const { return p->perm[2][i]; }
+    __device__ V3<T> vec(uint32_t i) const { return V3<T>(p->ranvec[i][0], p->ranvec[i][1], p->ranvec[i][2]); }
+};
+template <class T> struct PerlinLds {
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__)
+    PerlinGlobal<T> g;
+    __device__ explicit PerlinLds(const DPerlin<T>* q) : g{q} {}
+    __device__ uint32_t px(uint32_t i) const { return g.px(i); }
+    __device__ uint32_t py(uint32_t i) const { return g.py(i); }
+    __device__ uint32_t pz(uint32_t i) const { return g.pz(i); }
+    __device__ V3<T> vec(uint32_t i) const { return g.vec(i); }
+#else
+    // explicit LDS address space: ds_read_* instead of flat loads
+    typedef const __attribute__((address_space(3))) uint8_t* lds_u8;
+    typedef const __attribute__((address_space(3))) T* lds_t;
+    lds_t v;
+    lds_u8 b;
+    __device__ explicit PerlinLds(const DPerlin<T>* q)
+        : v((lds_t)(uintptr_t)(uint32_t)(uintptr_t)q), b((lds_u8)(uintptr_t)(uint32_t)(uintptr_t)q + sizeof(T) * 256u * DPerlin<T>::kStride) {}
+    __device__ uint32_t px(uint32_t i) const { return b[i]; }
+    __device__ uint32_t py(uint32_t i) const { return b[256u + i]; }
+    __device__ uint32_t pz(uint32_t i) const { return b[512u + i]; }
+    __device__ V3<T> vec(uint32_t i) const {
+        constexpr uint32_t S = DPerlin<T>::kStride;
+        return V3<T>(v[S * i], v[S * i + 1u], v[S * i + 2u]);
+    }
+#endif
+};
+
 // src/texture.rs:139-165
-template <class T> __device__ inline T perlin_noise(const DPerlin<T>& pl, V3<T> p) {
+template <class T, class P> __device__ inline T perlin_noise(const P& pl, V3<T> p) {
     T fx = rfloor(p.x), fy = rfloor(p.y), fz = rfloor(p.z);
     T u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int32_t i = as_i32(fx), j = as_i32(fy), k = as_i32(fz);
     T uu = u * u * (T(3) - T(2) * u);
     T vv = v * v * (T(3) - T(2) * v);
     T ww = w * w * (T(3) - T(2) * w);
+    const uint32_t hx[2] = {pl.px((uint32_t)i & 255u), pl.px((uint32_t)(i + 1) & 255u)};
+    const uint32_t hy[2] = {pl.py((uint32_t)j & 255u), pl.py((uint32_t)(j + 1) & 255u)};
+    const uint32_t hz[2] = {pl.pz((uint32_t)k & 255u), pl.pz((uint32_t)(k + 1) & 255u)};
     T accum = T(0);
 #pragma unroll
     for (int di = 0; di < 2; di++)
@@ -734,22 +780,20 @@ template <class T> __device__ inline T perlin_noise(const DPerlin<T>& pl, V3<T> 
         for (int dj = 0; dj < 2; dj++)
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
-                uint32_t idx = (uint32_t)pl.perm_x[(uint32_t)(i + di) & 255u] ^ (uint32_t)pl.perm_y[(uint32_t)(j + dj) & 255u] ^
-                               (uint32_t)pl.perm_z[(uint32_t)(k + dk) & 255u];
-                V3<T> c(pl.ranvec[idx]);
+                V3<T> c = pl.vec(hx[di] ^ hy[dj] ^ hz[dk]);
                 accum += (T(di) * uu + (T(1) - T(di)) * (T(1) - uu)) * (T(dj) * vv + (T(1) - T(dj)) * (T(1) - vv)) *
                          (T(dk) * ww + (T(1) - T(dk)) * (T(1) - ww)) * dot(c, V3<T>(u - T(di), v - T(dj), w - T(dk)));
             }
     return accum;
 }
 // src/texture.rs:166-176
-template <class T> __device__ inline T perlin_turb(const DPerlin<T>& pl, V3<T> p, int depth) {
+template <class T, class P> __device__ inline T perlin_turb(const P& pl, V3<T> p, int depth) {
     T accum = T(0);
     V3<T> temp_p = p;
     T weight = T(1);
 #pragma nounroll
     for (int i = 0; i < depth; i++) {
-        accum += weight * perlin_noise(pl, temp_p);
+        accum += weight * perlin_noise<T, P>(pl, temp_p);
         weight *= T(0.5);
         temp_p = temp_p * T(2);
     }
@@ -771,7 +815,12 @@ template <class T, uint32_t F> __device__ inline V3<T> texture_value(const DScen
                 tex = (as_i32(u / T(0.01)) % 2 == as_i32(v / T(0.01)) % 2) ? t.odd : t.even;
                 break;
             case 3:                                                                  // texture.rs:58-60
-                return V3<T>(T(1), T(1), T(1)) * T(0.5) * (T(1) + rsin(t.scale * p.z + T(10) * perlin_turb(sc.perlins[t.table], p, 7)));
+            {
+                T turb;
+                if (has<F>(F_NOISE) && t.table < sc.n_perlin_lds) turb = perlin_turb<T>(PerlinLds<T>(sc.perlin_lds + t.table), p, 7);
+                else turb = perlin_turb<T>(PerlinGlobal<T>{&sc.perlins[t.table]}, p, 7);
+                return V3<T>(T(1), T(1), T(1)) * T(0.5) * (T(1) + rsin(t.scale * p.z + T(10) * turb));
+            }
             default: {                                                               // texture.rs:77-97
                 const DImage& im = sc.images[t.table];
                 T uc = u < T(0) ? T(0) : (u > T(1) ? T(1) : u);

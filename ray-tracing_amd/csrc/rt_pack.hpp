@@ -219,8 +219,10 @@ inline uint32_t scene_features(const RtSceneDesc* d) {
         bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
         if (textured && texture_needs_uv(d, m.texture, 0)) f |= F_UV;
     }
-    for (uint32_t i = 0; i < d->n_textures; i++)
+    for (uint32_t i = 0; i < d->n_textures; i++) {
         if (d->textures[i].kind != RT_TEX_SOLID) f |= F_TEXTURED;
+        if (d->textures[i].kind == RT_TEX_NOISE) f |= F_NOISE;
+    }
     if (d->n_lights) f |= F_LIGHTS;
     return f;
 }
@@ -253,8 +255,9 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
         const RtPerlin& p = d->perlins[i];
         DPerlin<T> o;
         for (int k = 0; k < 256; k++) {
-            o.perm_x[k] = (uint8_t)p.perm_x[k]; o.perm_y[k] = (uint8_t)p.perm_y[k]; o.perm_z[k] = (uint8_t)p.perm_z[k];
+            o.perm[0][k] = (uint8_t)p.perm_x[k]; o.perm[1][k] = (uint8_t)p.perm_y[k]; o.perm[2][k] = (uint8_t)p.perm_z[k];
             for (int c = 0; c < 3; c++) o.ranvec[k][c] = (T)p.ranvec[k][c];
+            if (DPerlin<T>::kStride > 3) o.ranvec[k][DPerlin<T>::kStride - 1] = T(0);
         }
         h.perlins.push_back(o);
     }
@@ -325,6 +328,9 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     out.n_bvh = (uint32_t)h.bvh.size();
     out.n_bvh_lds = 0;
     out.bvh_lds = nullptr;
+    out.n_perlins = d->n_perlins;
+    out.n_perlin_lds = 0;
+    out.perlin_lds = nullptr;
     out.n_world = d->n_world;
     out.n_lights = d->n_lights;
     for (int k = 0; k < 3; k++) out.background[k] = (T)d->background[k];

@@ -6,7 +6,8 @@
 namespace rt {
 constexpr uint32_t V_CORNELL = F_XFORM | F_SPHERE | F_RECT | F_CUBOID | F_DIELECTRIC | F_LIGHTS;           // cornell_box
 constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                                                          // cornell_smoke
-constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, perlin
+constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, checker spheres
+constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                                               // two_perlin_spheres
 
 // Register budget of the render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
 // SIMD: 2 -> 256, 3 -> 168, 4 -> 128).  Chosen from measurements (profiles/): the no-BVH f64
@@ -18,22 +19,34 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
     return sizeof(T) == 8 ? (((F & F_BVH) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
 #endif
 }
+// LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
+// register budget does: f64 2 blocks x (64 KB + 6 KB tile sums [+ 8.75 KB Perlin table]), f32 3 blocks x
+// (44 KB [39 KB + 4.75 KB Perlin table] + 6 KB) of 160 KB.
+template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
+#ifdef RT_LDS_BVH_ENTRIES
+    return RT_LDS_BVH_ENTRIES;
+#else
+    return sizeof(T) == 8 ? 2048u : ((F & F_NOISE) ? 1248u : 1408u);
+#endif
+}
+// Perlin tables staged in LDS (scenes.rs uses one per NoiseTexture: two_perlin_spheres 2, final_scene 1)
+template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin_tables() {
+    return (F & F_NOISE) ? ((F & F_BVH) ? 1u : 2u) : 0u;
+}
 // The block-sorted kernel waits at two barriers per iteration: it wants more resident waves than the wave-level
-// kernel even at the price of a few spills (f64 Cornell: +14 % at 4 waves/SIMD vs 3; its 39.5 KB of LDS admit 4 blocks).
+// kernel even at the price of a few spills (f64 Cornell: +14 % at 4 waves/SIMD vs 3; its 39.5 KB of LDS admit 4
+// blocks per CU).  The figure must be one the kernel's LDS admits — the compiler drops an unreachable request
+// altogether and then allocates up to 256 registers.
+template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds_bytes() {
+    return ((F & F_UV) ? 15u : 13u) * 256u * (uint32_t)sizeof(T) + 7u * 1024u + 6144u + 68u +
+           lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
+}
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
 #ifdef RT_WAVES_PER_SIMD_SORTED
     return RT_WAVES_PER_SIMD_SORTED;
 #else
-    return 4;
-#endif
-}
-// LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
-// register budget does: f64 2 blocks x (64 KB + 6 KB tile sums), f32 3 blocks x (44 KB + 6 KB) of 160 KB.
-template <class T> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
-#ifdef RT_LDS_BVH_ENTRIES
-    return RT_LDS_BVH_ENTRIES;
-#else
-    return sizeof(T) == 8 ? 2048u : 1408u;
+    // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
+    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (163840u / sorted_lds_bytes<T, F>() >= 4u ? 4 : (int)(163840u / sorted_lds_bytes<T, F>()));
 #endif
 }
 }  // namespace rt
@@ -43,5 +56,6 @@ template <class T> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
         if (((features) & ~rt::V_CORNELL) == 0) { CALL(rt::V_CORNELL); }     \
         else if (((features) & ~rt::V_SMOKE) == 0) { CALL(rt::V_SMOKE); }    \
         else if (((features) & ~rt::V_SPHERES) == 0) { CALL(rt::V_SPHERES); }\
+        else if (((features) & ~rt::V_NOISE) == 0) { CALL(rt::V_NOISE); }    \
         else { CALL(rt::F_ALL); }                                            \
     } while (0)

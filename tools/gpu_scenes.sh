@@ -17,3 +17,7 @@ run cornell_smoke --scene cornell_smoke --spp-per-step 64 --steps 2 --warmup 1
 run earth --scene earth --spp-per-step 256 --steps 2 --warmup 1
 run two_perlin_spheres --scene two_perlin_spheres --spp-per-step 64 --steps 2 --warmup 1
 run final_scene --scene final_scene --spp-per-step 8 --steps 2 --warmup 1
+if [ "${NOSORT:-0}" = 1 ]; then
+  run earth_nosort --scene earth --spp-per-step 256 --steps 2 --warmup 1 --no-sort
+  run two_perlin_nosort --scene two_perlin_spheres --spp-per-step 64 --steps 2 --warmup 1 --no-sort
+fi
