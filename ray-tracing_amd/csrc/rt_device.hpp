@@ -30,6 +30,24 @@ extern "C" unsigned long long g_sim_counters[8];
 #define RT_SIM_COUNT(i) ((void)0)
 #endif
 
+// Profiling build (-DRT_PHASE_CLOCK, tools/build_ab.py): per-wave cycle and active-lane sums per phase of the
+// wave-level render kernel, printed for a few blocks.  Slots: [i] cycles, [8+i] cycles x active lanes.
+#if defined(RT_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+__device__ inline unsigned long long* rt_pc() { __shared__ unsigned long long pc[4][16]; return pc[threadIdx.x >> 6]; }
+#define RT_PCB() unsigned long long pc_t_ = __builtin_readcyclecounter()
+#define RT_PCE(i)                                                                                        \
+    do {                                                                                                 \
+        const unsigned long long n_ = __builtin_readcyclecounter(), m_ = __builtin_amdgcn_ballot_w64(true); \
+        if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) {                                      \
+            rt_pc()[i] += n_ - pc_t_; rt_pc()[8 + (i)] += (n_ - pc_t_) * (unsigned long long)__builtin_popcountll(m_); \
+        }                                                                                                \
+        pc_t_ = __builtin_readcyclecounter();                                                            \
+    } while (0)
+#else
+#define RT_PCB() ((void)0)
+#define RT_PCE(i) ((void)0)
+#endif
+
 namespace rt {
 
 // ------------------------------------------------------------------------------------------
@@ -99,6 +117,12 @@ template <class T> struct DScene {
     uint32_t n_world, n_lights;
     T background[3];
     DCamera<T> cam;
+};
+
+// Job list of the persistent render kernel: job j = sample chunk j / n_tiles of 8x8 tile j % n_tiles
+struct JobGrid {
+    uint32_t* counter;  // zeroed before the launch; waves draw jobs with atomicAdd until it passes n_jobs
+    uint32_t tiles_x, n_tiles, n_chunks, chunk_spp, n_jobs;
 };
 
 struct RenderArgs {
@@ -509,6 +533,7 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
         int prim = -1;
         float tmax_lo, tmax_hi;
         widen<float>((float)closest, tmax_lo, tmax_hi);
+        RT_PCB();
         while (i != end) {
             DBvhLite e;
             if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
@@ -534,6 +559,7 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
             }
             i = pass ? i + 1 : e.skip;
         }
+        RT_PCE(2);
         if (i == end) break;
         T t; int side;
         RT_SIM_COUNT(2);
@@ -542,6 +568,7 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
             any = true; closest = t; prim_out = prim; side_out = side;
         }
         i = i + 1;
+        RT_PCE(3);
     }
     t_out = closest;
     return any;

@@ -30,6 +30,12 @@ struct RtScene {
     rt::DScene<double> s64;
     std::vector<void*> allocs;
     uint32_t n_prims = 0;
+    // job counters of the persistent render kernel: a ring, one word per launch, so that launches queued on
+    // different streams do not share one (64 launches in flight per scene at most)
+    static constexpr uint32_t kCounters = 64;
+    uint32_t* d_counters = nullptr;
+    uint32_t next_counter = 0;
+    uint32_t cu_count = 0;
 };
 
 namespace {
@@ -120,6 +126,17 @@ int rt_scene_create(const RtSceneDesc* desc, RtScene** out) {
     if (rc == RT_OK) rc = upload(sc, imgs, &d_images);
     if (rc == RT_OK) rc = build_device_scene<float>(sc, desc, d_images, sc->s32);
     if (rc == RT_OK) rc = build_device_scene<double>(sc, desc, d_images, sc->s64);
+    if (rc == RT_OK) {
+        hipDeviceProp_t prop;
+        void* d = nullptr;
+        if (hipGetDeviceProperties(&prop, sc->device) != hipSuccess || hipMalloc(&d, RtScene::kCounters * sizeof(uint32_t)) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "hipMalloc(job counters) failed");
+        } else {
+            sc->allocs.push_back(d);
+            sc->d_counters = (uint32_t*)d;
+            sc->cu_count = (uint32_t)prop.multiProcessorCount;
+        }
+    }
     if (rc != RT_OK) { rt_scene_destroy(sc); return rc; }
     *out = sc;
     return RT_OK;
@@ -163,8 +180,10 @@ int rt_render(RtScene* scene, const RtRenderParams* params, float* d_accum, uint
     if ((rc = make_args(params, a))) return rc;
     if (!d_accum) return fail(RT_ERR_INVALID, "d_accum is NULL");
     if (a.spp_count == 0) return RT_OK;
-    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, (params->flags & RT_RENDER_NO_SORT) != 0, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
-    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, (params->flags & RT_RENDER_NO_SORT) != 0, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
+    const rt::LaunchCtx ctx{scene->d_counters + (scene->next_counter++ % RtScene::kCounters), scene->cu_count};
+    const bool no_sort = (params->flags & RT_RENDER_NO_SORT) != 0;
+    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
+    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
     else return fail(RT_ERR_INVALID, "unknown precision");
     return RT_OK;
 }

@@ -7,8 +7,11 @@
 
 namespace rt {
 
-template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, bool no_sort, float* d_accum,
-                                           unsigned long long* d_stats, hipStream_t stream);
+// What a render launch needs from the scene handle besides the scene: a zeroable device word for the persistent
+// kernel's job counter (one per launch in flight) and the device's CU count.
+struct LaunchCtx { uint32_t* job_counter; uint32_t cu_count; };
+template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, bool no_sort, const LaunchCtx& ctx,
+                                           float* d_accum, unsigned long long* d_stats, hipStream_t stream);
 template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t features, uint32_t width, uint32_t height, double time,
                                                    double medium_xi, int32_t* d_ids, double* d_t, hipStream_t stream);
 template <class T> hipError_t launch_sample_pixel(const DScene<T>& sc, uint32_t features, const RenderArgs& a, uint32_t x, uint32_t y,

@@ -277,10 +277,14 @@ template <class T, uint32_t F>
 __device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts) {
     HitRecord<T> rec;
     uint32_t mat_index = 0;
+    RT_PCB();
     const int next = segment_cast<T, F>(sc, st, max_depth, rng, n_casts, rec, mat_index);
+    RT_PCE(1);  // includes the traversal slots 2, 3
     if (next == NEXT_DONE) return true;
-    if (next == NEXT_LAMBERT) { shade_lambert<T, F>(sc, st, rec, mat_index, rng); return false; }
-    return shade_specular<T, F>(sc, st, rec, mat_index, rng);
+    if (next == NEXT_LAMBERT) { shade_lambert<T, F>(sc, st, rec, mat_index, rng); RT_PCE(4); return false; }
+    const bool done = shade_specular<T, F>(sc, st, rec, mat_index, rng);
+    RT_PCE(5);
+    return done;
 }
 
 // Fresh camera path for sample (u,v): src/ray_tracing.rs:103
