@@ -24,7 +24,10 @@ def main(argv=None):
     ap.add_argument("--precision", default="f64", choices=("f64", "f32"))
     ap.add_argument("--spp-per-launch", type=int, default=256)
     ap.add_argument("--out", default="output/ray_tracing.png")  # ray_tracing.rs:133
-    ap.add_argument("--save-accum", default="", help="also save the linear float accumulation buffer (.npy): a progressive checkpoint")
+    ap.add_argument("--save-accum", default="", help="also save the linear float accumulation buffer (.npy)")
+    ap.add_argument("--checkpoint", default="", help="progressive rendering: write the summed accumulation buffer here after every pass")
+    ap.add_argument("--pass-spp", type=int, default=0, help="samples per pass (all GPUs together) between checkpoints; default: spp/8")
+    ap.add_argument("--resume", action="store_true", help="continue the render recorded in --checkpoint (same scene, seed, size, depth)")
     a = ap.parse_args(argv)
 
     import torch
@@ -48,9 +51,15 @@ def main(argv=None):
     stats = torch.zeros(4, dtype=torch.int64, device=f"cuda:{local}")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = rt.render(ds, a.width, a.height, a.spp, seed=a.seed, max_depth=a.depth, precision=a.precision,
-                    spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
-                    all_reduce=dist.all_reduce if world > 1 else None, stats=stats)
+    if a.checkpoint:
+        acc, _ = rt.render_progressive(ds, a.width, a.height, a.spp, a.pass_spp or max(1, a.spp // 8), seed=a.seed, max_depth=a.depth,
+                                       precision=a.precision, spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
+                                       all_reduce=dist.all_reduce if world > 1 else None, stats=stats, checkpoint=a.checkpoint,
+                                       resume=a.resume, scene_name=a.scene)
+    else:
+        acc = rt.render(ds, a.width, a.height, a.spp, seed=a.seed, max_depth=a.depth, precision=a.precision,
+                        spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
+                        all_reduce=dist.all_reduce if world > 1 else None, stats=stats)
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t0
     if world > 1:

@@ -4,10 +4,12 @@ render kernels, (all-reduce,) resolve.  Replaces `run_ray_tracing` of the refere
 (src/ray_tracing.rs:95-118) runs in librt_hip.so.  PyTorch is used for device memory, streams and
 torch.distributed only."""
 import ctypes as C
+import json
 import os
 import struct
 import zlib
 
+import numpy as np
 import torch
 
 from . import _ffi
@@ -178,6 +180,87 @@ def render(scene, width, height, spp, seed=DEFAULT_SEED, max_depth=50, precision
     if all_reduce is not None and world_size > 1:
         all_reduce(accum)
     return accum
+
+
+# ---- progressive rendering + checkpoints of the accumulation buffer -------------------------
+# The reference renders one image in one go and keeps nothing (src/ray_tracing.rs:95-133).  Here samples are
+# keyed by (seed, pixel, sample index), so a render is a SUM over sample ranges: it can be done in passes,
+# the linear float sums written out between passes, and continued later — by any number of GPUs — to the
+# same image an uninterrupted render gives.
+CKPT_MAGIC = b"RTACCUM1"
+
+
+def save_checkpoint(path, accum, meta):
+    """accum: [H, W, 3] f32 linear radiance SUMS of samples [0, meta['spp_done']).  Written atomically."""
+    arr = accum.detach().cpu().numpy() if hasattr(accum, "detach") else accum
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    if arr.ndim != 3 or arr.shape[2] != 3:
+        raise ValueError("accum must be [H, W, 3]")
+    head = dict(meta)
+    head.update(height=int(arr.shape[0]), width=int(arr.shape[1]))
+    blob = json.dumps(head, sort_keys=True).encode()
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(CKPT_MAGIC + struct.pack("<II", len(blob), zlib.crc32(arr.tobytes()) & 0xFFFFFFFF) + blob + arr.tobytes())
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path):
+    """-> (numpy [H, W, 3] f32, meta dict).  Raises ValueError on a damaged or foreign file."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:8] != CKPT_MAGIC or len(raw) < 16:
+        raise ValueError(f"{path}: not an accumulation-buffer checkpoint")
+    n, crc = struct.unpack("<II", raw[8:16])
+    meta = json.loads(raw[16:16 + n].decode())
+    body = raw[16 + n:]
+    h, w = int(meta["height"]), int(meta["width"])
+    if len(body) != h * w * 12 or (zlib.crc32(body) & 0xFFFFFFFF) != crc:
+        raise ValueError(f"{path}: truncated or corrupted checkpoint")
+    return np.frombuffer(body, dtype=np.float32).reshape(h, w, 3).copy(), meta
+
+
+def render_progressive(scene, width, height, spp, pass_spp, seed=DEFAULT_SEED, max_depth=50, precision="f32", spp_per_launch=None,
+                       rank=0, world_size=1, all_reduce=None, stats=None, checkpoint=None, resume=False, scene_name="", on_pass=None):
+    """Render samples [0, spp) in passes of pass_spp samples; each pass is sharded over the ranks like render().
+    After every pass the summed buffer is written to `checkpoint` (rank 0); with resume=True an existing
+    checkpoint of the same frame is continued from its spp_done.  on_pass(spp_done, summed accum or None) is
+    called on every rank after each pass.  Returns (accum summed over ranks, spp rendered in total)."""
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=scene.torch_device)
+    ident = {"scene": scene_name, "seed": int(seed), "max_depth": int(max_depth), "width": int(width), "height": int(height)}
+    done = 0
+    if resume and checkpoint and os.path.exists(checkpoint):
+        arr, meta = load_checkpoint(checkpoint)
+        for k, v in ident.items():
+            if meta.get(k) != v:
+                raise ValueError(f"checkpoint {checkpoint} is of another render: {k} = {meta.get(k)!r}, wanted {v!r}")
+        done = int(meta["spp_done"])
+        if rank == 0:  # the sums so far enter the all-reduce once
+            accum += torch.from_numpy(arr).to(accum.device)
+    while done < spp:
+        n = min(int(pass_spp), spp - done)
+        begin, count = spp_shard(n, rank, world_size)
+        step = spp_per_launch or count or 1
+        s = done + begin
+        while s < done + begin + count:
+            k = min(step, done + begin + count - s)
+            scene.render_into(accum, s, k, seed=seed, max_depth=max_depth, precision=precision, stats=stats)
+            s += k
+        done += n
+        total = None
+        if (checkpoint or on_pass) and done < spp:
+            total = accum.clone()
+            if all_reduce is not None and world_size > 1:
+                all_reduce(total)
+            if checkpoint and rank == 0:
+                save_checkpoint(checkpoint, total, dict(ident, spp_done=done, precision=precision))
+        if on_pass:
+            on_pass(done, total)
+    if all_reduce is not None and world_size > 1:
+        all_reduce(accum)
+    if checkpoint and rank == 0:
+        save_checkpoint(checkpoint, accum, dict(ident, spp_done=done, precision=precision))
+    return accum, done
 
 
 def write_png(path, rgb):
