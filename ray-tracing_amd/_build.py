@@ -23,7 +23,7 @@ UNITS = [
     ("rt_kernels_f32.hip", ["-O3", "-ffp-contract=fast"]),
     ("rt_hip.hip", ["-O2"]),
 ]
-HOST_SRC = ["scene_api.cpp", "scenes.cpp", "flatten.cpp", "capi.cpp"]
+HOST_SRC = ["scene_api.cpp", "scenes.cpp", "flatten.cpp", "jpeg.cpp", "capi.cpp"]
 HOST_FLAGS = ["-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-shared"]
 
 

@@ -1,4 +1,5 @@
 // capi.cpp — include/rt_host.h: build a reference scene, flatten it, hand out the RtSceneDesc.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -76,5 +77,22 @@ int rth_scene_roundtrip_check(const RthScene* scene) {
         return -1;
     }
 }
+
+// Decode an image file the way ImageTexture::new does (texture.rs:68-74): baseline JPEG or binary PPM -> RGB8.
+int rth_image_load(const char* path, uint8_t** rgb, uint32_t* width, uint32_t* height) {
+    if (!path || !rgb || !width || !height) { g_error = "NULL argument"; return -1; }
+    try {
+        std::shared_ptr<const rth::RgbImage> im = rth::load_image(path);
+        *rgb = (uint8_t*)std::malloc(im->rgb.size() ? im->rgb.size() : 1);
+        if (!*rgb) { g_error = "out of memory"; return -1; }
+        std::memcpy(*rgb, im->rgb.data(), im->rgb.size());
+        *width = im->width; *height = im->height;
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+void rth_image_free(uint8_t* rgb) { std::free(rgb); }
 
 }  // extern "C"

@@ -79,10 +79,27 @@ Perlin::Perlin(SceneRng& rng) {
     for (int i = 0; i < 256; i++) ranvec.push_back(rng.random_vec3(-1.0, 1.0).unit());
 }
 
-ImageTexture::ImageTexture(const std::string& filename) : Texture(IMAGE) {
+ImageTexture::ImageTexture(const std::string& filename) : Texture(IMAGE) { img = load_image(filename); }
+
+// texture.rs:68-74: image::open(filename).to_rgb().  JPEG (baseline, jpeg.cpp) or 8-bit binary PPM, told apart by content.
+std::shared_ptr<const RgbImage> load_image(const std::string& filename) {
     FILE* f = std::fopen(filename.c_str(), "rb");
     if (!f) throw std::runtime_error("ImageTexture:failed to open file " + filename);
     auto raster = std::make_shared<RgbImage>();
+    unsigned char magic[2] = {0, 0};
+    if (std::fread(magic, 1, 2, f) == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
+        std::vector<uint8_t> data;
+        std::fseek(f, 0, SEEK_END);
+        const long size = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        data.resize(size > 0 ? (size_t)size : 0);
+        const bool read_ok = std::fread(data.data(), 1, data.size(), f) == data.size();
+        std::fclose(f);
+        std::string err;
+        if (!read_ok || !decode_jpeg(data.data(), data.size(), *raster, err)) throw std::runtime_error("ImageTexture: " + filename + ": " + (read_ok ? err : "read error"));
+        return raster;
+    }
+    std::fseek(f, 0, SEEK_SET);
     int maxval = 0;
     bool ok = std::fscanf(f, "P6 %u %u %d", &raster->width, &raster->height, &maxval) == 3 && maxval == 255 && std::fgetc(f) != EOF;
     if (ok) {
@@ -90,8 +107,8 @@ ImageTexture::ImageTexture(const std::string& filename) : Texture(IMAGE) {
         ok = std::fread(raster->rgb.data(), 1, raster->rgb.size(), f) == raster->rgb.size();
     }
     std::fclose(f);
-    if (!ok) throw std::runtime_error("ImageTexture: " + filename + " is not an 8-bit binary PPM");
-    img = raster;
+    if (!ok) throw std::runtime_error("ImageTexture: " + filename + " is neither a baseline JPEG nor an 8-bit binary PPM");
+    return raster;
 }
 
 std::optional<Aabb> ObjectList::bounding_box(double t1, double t2) const {

@@ -79,6 +79,9 @@ struct RgbImage {
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> rgb;
 };
+// jpeg.cpp: baseline JPEG -> RGB8 (what `image::open(..).to_rgb()` does for images/earthmap.jpg, texture.rs:70-72)
+bool decode_jpeg(const uint8_t* data, size_t n, RgbImage& out, std::string& err);
+std::shared_ptr<const RgbImage> load_image(const std::string& filename);
 struct Texture {
     enum Kind { SOLID, CHECKER_UV, CHECKER, NOISE, IMAGE } kind;
     explicit Texture(Kind k) : kind(k) {}
@@ -104,7 +107,7 @@ struct NoiseTexture : Texture {
 };
 struct ImageTexture : Texture {
     std::shared_ptr<const RgbImage> img;
-    // texture.rs:68-74 decodes a JPEG; this host reads the pre-decoded raster (binary PPM)
+    // texture.rs:68-74: a baseline JPEG (decoded by jpeg.cpp) or a pre-decoded raster (binary PPM)
     explicit ImageTexture(const std::string& filename);
     explicit ImageTexture(std::shared_ptr<const RgbImage> i) : Texture(IMAGE), img(std::move(i)) {}
 };
