@@ -488,13 +488,113 @@ __device__ inline DBvhLite lds_entry(const DBvhLite* table, int i) {
 #endif
 }
 
-// Geometry of an instance: one primitive, or a threaded-BVH walk (src/bvh.rs:114-129: box test,
-// left subtree, then right subtree with t_max = best so far; strict/inclusive tie rules of the
-// leaf primitives decide equal-t replacement; the visiting ORDER is the reference's, so ties
-// resolve identically).  "while-while" form: every lane first advances through internal nodes
-// until it stands on a leaf (or is done), then the wave tests leaves together, so box tests and
-// primitive tests are not serialised against each other.  Node records come from LDS for the
-// entries the render kernel staged there, else from global memory (L2).
+// A threaded-BVH walk in progress (src/bvh.rs:114-129: box test, left subtree, then right subtree with
+// t_max = best so far; strict/inclusive tie rules of the leaf primitives decide equal-t replacement; the
+// visiting ORDER is the reference's, so ties resolve identically).
+template <class T> struct Walk {
+    int i, end;        // next entry, one past the instance's subtree
+    T closest, t_min;
+    bool any, leaf_cull;
+    int prim, side;
+    RayR<float> r;     // per-ray constants of the first-level box classification
+    RayR<T> r2;        // second level (f64 mode only)
+};
+template <class T, uint32_t F>
+__device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T> o, V3<T> d, T time, T t_min, T t_max, Walk<T>& w) {
+    w.any = false;
+    w.closest = t_max;
+    w.t_min = t_min;
+    w.prim = -1;
+    w.side = 0;
+    w.i = sc.bvh_root_entry[geom_index];
+    float B;
+    {
+        const DBvhLite& root = sc.bvh_lite[w.i];
+        w.end = root.skip;
+        B = fabsf(root.mn[0]);
+        B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
+        B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
+    }
+    ray_consts<float, T>(w.r, o, d, t_min, B, 3.814697265625e-06f);  // 2^-18 (|o| + B): f32 rounding of o, box, products
+    if (sizeof(T) == 8) {
+        ray_consts<T, T>(w.r2, o, d, t_min, (T)B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
+    }
+    // leaves carry their primitive's own box: most leaf visits are misses (measured 94 % in random_scene) and
+    // an exact sphere / cuboid test costs 70-270 f64 instructions.  Moving spheres' boxes cover sc.time_lo..time_hi.
+#ifdef RT_DBG_NO_LEAF_CULL
+    w.leaf_cull = false;
+#else
+    w.leaf_cull = time >= sc.time_lo && time <= sc.time_hi;
+#endif
+}
+// Continue the walk.  "while-while" form with three kinds of step, each run for all lanes that want it before the
+// next kind runs, so that box tests, the rare undecided nodes and the primitive tests are not serialised against
+// each other inside a wave:
+//   A  first-level classification, until the lane stands on an undecided node, on a leaf to test, or is done
+//   B  undecided internal nodes: second level (f64), then the reference's exact test
+//   C  leaf primitive tests
+// The per-lane sequence of decisions is the sequential one; only the interleaving between lanes differs.
+// Node records come from LDS for the entries the render kernel staged there, else from global memory (L2).
+template <class T, uint32_t F>
+__device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, T time) {
+    const int n_lds = (int)sc.n_bvh_lds;
+    int i = w.i;
+    const int end = w.end;
+    T closest = w.closest;
+    for (;;) {
+        int prim = -1;
+        bool undecided = false;
+        float tmax_lo, tmax_hi;
+        widen<float>((float)closest, tmax_lo, tmax_hi);
+        RT_PCB();
+        DBvhLite e;
+        e.skip = end;
+        while (i != end) {
+            if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
+            prim = e.prim;
+            const int c = aabb_classify<float, float>(e.mn, e.mx, w.r, tmax_lo, tmax_hi);
+            RT_SIM_COUNT(0);
+            if (prim >= 0) {
+                // a leaf the first level cannot rule out is tested (its box only serves to skip certain misses)
+                if (c != 0 || !w.leaf_cull) break;
+                RT_SIM_COUNT(4);
+                i = i + 1;  // certainly missed: next entry
+                continue;
+            }
+            if (c == 2) { undecided = true; break; }
+            i = c == 1 ? i + 1 : e.skip;
+        }
+        RT_PCE(2);
+        if (i == end) break;
+        if (undecided) {
+            int c = 2;
+            const DBvhEntry<T>& ex = sc.bvh[i];
+            if (sizeof(T) == 8) {  // second level: f64 ray against the exact box
+                RT_SIM_COUNT(5);
+                c = aabb_classify<T, T>(ex.mn, ex.mx, w.r2, closest, closest);
+            }
+            bool pass = c == 1;
+            if (c == 2) {  // rare: the reference's exact decision on the exact box
+                RT_SIM_COUNT(1);
+                pass = aabb_hit(ex.mn, ex.mx, o, d, w.t_min, closest);
+            }
+            i = pass ? i + 1 : e.skip;
+        } else {
+            T t; int side;
+            RT_SIM_COUNT(2);
+            if (prim_hit<T, F>(sc.prims[prim], o, d, time, w.t_min, closest, t, side)) {
+                RT_SIM_COUNT(3);
+                w.any = true; closest = t; w.prim = prim; w.side = side;
+            }
+            i = i + 1;
+        }
+        RT_PCE(3);
+    }
+    w.i = i;
+    w.closest = closest;
+}
+
+// Geometry of an instance: one primitive, or a complete BVH walk.
 template <class T, uint32_t F>
 __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, T time,
                                 T t_min, T t_max, T& t_out, int& prim_out, int& side_out) {
@@ -502,76 +602,12 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
         prim_out = (int)geom_index;
         return prim_hit<T, F>(sc.prims[geom_index], o, d, time, t_min, t_max, t_out, side_out);
     }
-    bool any = false;
-    T closest = t_max;
-    int i = sc.bvh_root_entry[geom_index];
-    const int n_lds = (int)sc.n_bvh_lds;
-    // per-ray constants of the box classification
-    int end;
-    float B;
-    {
-        const DBvhLite& root = sc.bvh_lite[i];
-        end = root.skip;
-        B = fabsf(root.mn[0]);
-        B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
-        B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
-    }
-    RayR<float> r;
-    ray_consts<float, T>(r, o, d, t_min, B, 3.814697265625e-06f);  // 2^-18 (|o| + B): f32 rounding of o, box, products
-    RayR<T> r2;                                                    // second level, used in f64 mode only
-    if (sizeof(T) == 8) {
-        ray_consts<T, T>(r2, o, d, t_min, (T)B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
-    }
-    // leaves carry their primitive's own box: most leaf visits are misses (measured 94 % in random_scene) and
-    // an exact sphere / cuboid test costs 70-270 f64 instructions.  Moving spheres' boxes cover sc.time_lo..time_hi.
-#ifdef RT_DBG_NO_LEAF_CULL
-    const bool leaf_cull = false;
-#else
-    const bool leaf_cull = time >= sc.time_lo && time <= sc.time_hi;
-#endif
-    for (;;) {
-        int prim = -1;
-        float tmax_lo, tmax_hi;
-        widen<float>((float)closest, tmax_lo, tmax_hi);
-        RT_PCB();
-        while (i != end) {
-            DBvhLite e;
-            if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
-            prim = e.prim;
-            int c = aabb_classify<float, float>(e.mn, e.mx, r, tmax_lo, tmax_hi);
-            RT_SIM_COUNT(0);
-            if (sizeof(T) == 8 && c == 2 && prim < 0) {  // second level: f64 ray against the exact box
-                RT_SIM_COUNT(5);
-                const DBvhEntry<T>& ex = sc.bvh[i];
-                c = aabb_classify<T, T>(ex.mn, ex.mx, r2, closest, closest);
-            }
-            if (prim >= 0) {
-                if (c != 0 || !leaf_cull) break;  // test this leaf
-                RT_SIM_COUNT(4);
-                i = i + 1;                         // certainly missed: next entry
-                continue;
-            }
-            bool pass = c == 1;
-            if (c == 2) {  // rare: the reference's exact decision on the exact box
-                RT_SIM_COUNT(1);
-                const DBvhEntry<T>& ex = sc.bvh[i];
-                pass = aabb_hit(ex.mn, ex.mx, o, d, t_min, closest);
-            }
-            i = pass ? i + 1 : e.skip;
-        }
-        RT_PCE(2);
-        if (i == end) break;
-        T t; int side;
-        RT_SIM_COUNT(2);
-        if (prim_hit<T, F>(sc.prims[prim], o, d, time, t_min, closest, t, side)) {
-            RT_SIM_COUNT(3);
-            any = true; closest = t; prim_out = prim; side_out = side;
-        }
-        i = i + 1;
-        RT_PCE(3);
-    }
-    t_out = closest;
-    return any;
+    Walk<T> w;
+    walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w);
+    walk_run<T, F>(sc, w, o, d, time);
+    if (w.any) { prim_out = w.prim; side_out = w.side; }
+    t_out = w.closest;
+    return w.any;
 }
 
 // src/transforms.rs:15-17, 90-103: world ray -> object ray through the instance's wrapper chain.

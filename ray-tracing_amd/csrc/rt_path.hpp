@@ -186,18 +186,10 @@ enum : int { NEXT_LAMBERT = 0, NEXT_SPECULAR = 1, NEXT_DONE = 2 };
 
 // After the call: NEXT_DONE -> st.L is final.  Otherwise st.ray.ori is the hit point, st.ray.dir still
 // the INCOMING direction, rec.normal/u/v describe the hit and mat_index its material.
+// The part of a segment after the world scan: background / emission / hit record / what happens next.
 template <class T, uint32_t F>
-__device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts, HitRecord<T>& rec,
-                                   uint32_t& mat_index) {
-    if (st.seg >= max_depth) {  // depth <= 0 -> zero (:19-21); the multiply keeps NaN/inf throughput NaN
-        st.L = st.L + st.beta * T(0);
-        return NEXT_DONE;
-    }
-    st.seg++;
-    n_casts++;
-    Hit<T> h;
-    MediumXi mxi{&rng, 0.0};
-    if (!world_hit<T, F>(sc, st.ray, T(0.001), Lim<T>::max(), mxi, h)) {  // :22, :59
+__device__ inline int segment_post(const DScene<T>& sc, PathState<T>& st, bool any, const Hit<T>& h, HitRecord<T>& rec, uint32_t& mat_index) {
+    if (!any) {  // :22, :59
         st.L = st.L + elemul(st.beta, V3<T>(sc.background));
         return NEXT_DONE;
     }
@@ -215,6 +207,25 @@ __device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int ma
         return NEXT_DONE;
     }
     return NEXT_SPECULAR;
+}
+// Depth check of a new segment (:19-21).  false: the path ends here (st.L final).
+template <class T> __device__ inline bool segment_begin(PathState<T>& st, int max_depth, uint32_t& n_casts) {
+    if (st.seg >= max_depth) {  // depth <= 0 -> zero; the multiply keeps NaN/inf throughput NaN
+        st.L = st.L + st.beta * T(0);
+        return false;
+    }
+    st.seg++;
+    n_casts++;
+    return true;
+}
+template <class T, uint32_t F>
+__device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int max_depth, Rng& rng, uint32_t& n_casts, HitRecord<T>& rec,
+                                   uint32_t& mat_index) {
+    if (!segment_begin<T>(st, max_depth, n_casts)) return NEXT_DONE;
+    Hit<T> h;
+    MediumXi mxi{&rng, 0.0};
+    const bool any = world_hit<T, F>(sc, st.ray, T(0.001), Lim<T>::max(), mxi, h);
+    return segment_post<T, F>(sc, st, any, h, rec, mat_index);
 }
 
 // Lambertian: src/materials.rs:36-50 + ray_tracing.rs:25-43 (emitted == 0)
