@@ -370,8 +370,12 @@ __device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t
         if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
         return sphere_hit(center, radius, o, d, t_min, t_max, t_out);
     }
-    if (has<F>(F_RECT) && kind >= 2 && kind <= 4)
-        return rect_hit<T>((int)kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+    if (has<F>(F_RECT) && kind >= 2 && kind <= 4) {
+        // one copy per axis behind a wave-uniform branch: with a run-time axis the six component picks are 12 selects
+        if (kind == 2) return rect_hit<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+        if (kind == 3) return rect_hit<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+        return rect_hit<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+    }
     if (has<F>(F_CUBOID) && kind == 5) {  // six sides in tuple order, shrinking closest (src/objects.rs:458-485)
         bool any = false;
         T closest = t_max;

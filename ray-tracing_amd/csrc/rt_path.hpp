@@ -38,8 +38,11 @@ template <class T, uint32_t F> __device__ inline T prim_pdf_value(const DPrim<T>
         }
         return T(0);
     }
-    if (has<F>(F_RECT) && kind >= 2 && kind <= 4)
-        return rect_pdf<T>((int)kind - 2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], p.d[5], o, v);
+    if (has<F>(F_RECT) && kind >= 2 && kind <= 4) {  // one copy per axis (see prim_hit)
+        if (kind == 2) return rect_pdf<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], p.d[5], o, v);
+        if (kind == 3) return rect_pdf<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], p.d[5], o, v);
+        return rect_pdf<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], p.d[5], o, v);
+    }
     if (has<F>(F_CUBOID) && kind == 5) {  // src/objects.rs:492-500
         T weight = T(1) / T(6);
         T ans = T(0);
