@@ -188,6 +188,15 @@ def main():
         f32 = {"value": float(W) * H * S * k32 / dt32 / 1e6, "launch_ms": sum(lm32) / len(lm32)}
 
     if rank == 0:
+        # which render kernel the launcher picked (rt_kernels.inc: launch_render)
+        d = hs.desc
+        has_bvh = d.bvh.n_nodes > 0
+        has_medium = any(d.world[i].is_medium for i in range(d.n_world))
+        real = "double" if a.precision == "f64" else "float"
+        if not a.no_sort and not has_bvh and (d.n_lights > 0 or has_medium):
+            kernel_name = f"render_kernel_sorted<{real}> (block-sorted)"
+        else:
+            kernel_name = f"render_kernel<{real}> (persistent wave jobs)"
         fps = FLOPS_PER_SAMPLE.get(a.scene)
         samples_per_launch = float(W) * H * S
         roofline = None
@@ -197,7 +206,7 @@ def main():
             roofline = {
                 "bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[a.precision], 5), "traffic": None,
-                "kernel": f"render_kernel<{'double' if a.precision == 'f64' else 'float'}>",
+                "kernel": kernel_name,
                 "flops_per_sample": fps, "samples_per_launch": samples_per_launch, "launch_ms": round(mean_launch_s * 1e3, 4),
                 "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / mean_launch_s / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(hbm_bytes / mean_launch_s / 1e9 / PEAK_HBM_GBS, 7), "algorithmic_bytes_per_launch": hbm_bytes},
