@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Soak test on the GPU: randomly generated flat scenes (tests/flat_fuzz.py) through the C-ABI against the oracle
+rebuilt from the same description — probe ids/t bit-exact, frames sample-for-sample.  Not part of the test suite
+(the suite runs seeds 0..11); run by hand:  python tools/gpu_fuzz.py FIRST LAST"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ray_tracing_amd as rt  # noqa: E402
+from flat_fuzz import random_scene  # noqa: E402
+from oracle_lib import OracleScene  # noqa: E402
+
+first, last = int(sys.argv[1]), int(sys.argv[2])
+rt.init(0)
+bad = 0
+for seed in range(first, last):
+    host = rt.FlatHostScene(random_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    W, H, spp = 56, 40, 3
+    msg = []
+    for tm, xi in ((0.0, 0.5), (0.9, 0.2)):
+        ids, ts = ds.trace_primary(W, H, tm, xi, "f64")
+        oi, ot = oc.trace_primary(W, H, tm, xi)
+        if not (np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot)):
+            msg.append(f"probe t={tm}: {(ids.cpu().numpy() != oi).sum()} ids, {(ts.cpu().numpy() != ot).sum()} t differ")
+    ref, cnt = oc.render(W, H, 0, spp, threads=16)
+    for no_sort in (False, True):
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st, no_sort=no_sort)
+        got = acc.cpu().numpy().astype(np.float64)
+        close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2).mean()
+        dc = abs(int(st[1]) - cnt["casts"]) / max(cnt["casts"], 1)
+        if close < 0.995 or dc > 0.005:
+            msg.append(f"frame no_sort={no_sort}: {close:.4f} of pixels equal, casts {int(st[1])} vs {cnt['casts']}")
+    ds.close()
+    if msg:
+        bad += 1
+        print(f"seed {seed}: " + "; ".join(msg), flush=True)
+    elif seed % 20 == 0:
+        print(f"seed {seed} ok", flush=True)
+print(f"done: {last - first} scenes, {bad} with differences", flush=True)
+sys.exit(1 if bad else 0)
