@@ -7,6 +7,7 @@ namespace rt {
 constexpr uint32_t V_CORNELL = F_XFORM | F_SPHERE | F_RECT | F_CUBOID | F_DIELECTRIC | F_LIGHTS;           // cornell_box
 constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                                                          // cornell_smoke
 constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, checker spheres
+constexpr uint32_t V_SPHERES_FLAT = V_SPHERES & ~F_BVH;                                                      // earth, two_checker_spheres (no LDS node table)
 constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                                               // two_perlin_spheres
 
 // Register budget of the render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
@@ -16,7 +17,8 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
-    return sizeof(T) == 8 ? (((F & F_BVH) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
+    // f64 with (u,v) and texture code (the spheres variants): 168 registers spill 272 B per lane; 2 waves measured faster
+    return sizeof(T) == 8 ? (((F & F_BVH) == 0 && (F & F_UV) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
 #endif
 }
 // LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
@@ -55,6 +57,7 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
     do {                                                                     \
         if (((features) & ~rt::V_CORNELL) == 0) { CALL(rt::V_CORNELL); }     \
         else if (((features) & ~rt::V_SMOKE) == 0) { CALL(rt::V_SMOKE); }    \
+        else if (((features) & ~rt::V_SPHERES_FLAT) == 0) { CALL(rt::V_SPHERES_FLAT); } \
         else if (((features) & ~rt::V_SPHERES) == 0) { CALL(rt::V_SPHERES); }\
         else if (((features) & ~rt::V_NOISE) == 0) { CALL(rt::V_NOISE); }    \
         else { CALL(rt::F_ALL); }                                            \
