@@ -10,25 +10,28 @@ constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECT
 constexpr uint32_t V_SPHERES_FLAT = V_SPHERES & ~F_BVH;                                                      // earth, two_checker_spheres (no LDS node table)
 constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                                               // two_perlin_spheres
 
-// Register budget of the render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
-// SIMD: 2 -> 256, 3 -> 168, 4 -> 128).  Chosen from measurements (profiles/): the no-BVH f64
-// instantiations fit 168 without spilling and run 23 % faster at 3 waves than at 2.
+// Register budget of the persistent render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
+// SIMD: 2 -> 256, 3 -> 168, 4 -> 128), and the LDS budget of the staged BVH head (32-byte entries), sized so that
+// LDS admits as many blocks per CU as the register budget does.  All chosen from measurements (profiles/):
+//  * BVH walks are chains of dependent LDS fetches: they want resident waves more than they mind spills.
+//    spheres + BVH (random_scene): 4 waves with a 1024-entry head (32 KB + 6 KB tile sums per block) — f64 861 ->
+//    1173 Msamples/s against 2 waves / 2048 entries, f32 1232 -> 1414.  The generic variant (final_scene) stops at
+//    3 waves (f64 122 -> 144; at 4 its 128 registers spill it to half speed).
+//  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
+//    registers spill 272 B per lane (2 waves faster); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
-    // f64 with (u,v) and texture code (the spheres variants): 168 registers spill 272 B per lane; 2 waves measured faster
-    return sizeof(T) == 8 ? (((F & F_BVH) == 0 && (F & F_UV) == 0) ? 3 : 2) : (((F & F_BVH) == 0) ? 4 : 3);
+    if (F & F_BVH) return (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) ? 3 : 4;
+    return sizeof(T) == 8 ? ((F & F_UV) ? 2 : 3) : 4;
 #endif
 }
-// LDS budget of the staged BVH head (32-byte entries), sized so that LDS admits as many blocks per CU as the
-// register budget does: f64 2 blocks x (64 KB + 6 KB tile sums [+ 8.75 KB Perlin table]), f32 3 blocks x
-// (44 KB [39 KB + 4.75 KB Perlin table] + 6 KB) of 160 KB.
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
 #ifdef RT_LDS_BVH_ENTRIES
     return RT_LDS_BVH_ENTRIES;
 #else
-    return sizeof(T) == 8 ? 2048u : ((F & F_NOISE) ? 1248u : 1408u);
+    return (sizeof(T) == 4 && (F & F_NOISE)) ? 1248u : 1024u;  // f32 generic: 3 blocks x (39 KB + 4.75 KB Perlin table + 6 KB)
 #endif
 }
 // Perlin tables staged in LDS (scenes.rs uses one per NoiseTexture: two_perlin_spheres 2, final_scene 1)
