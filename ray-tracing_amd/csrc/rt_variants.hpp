@@ -18,13 +18,13 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 //    1173 Msamples/s against 2 waves / 2048 entries, f32 1232 -> 1414.  The generic variant (final_scene) stops at
 //    3 waves (f64 122 -> 144; at 4 its 128 registers spill it to half speed).
 //  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
-//    registers spill 272 B per lane (2 waves faster); f32 4 waves.
+//    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
     if (F & F_BVH) return (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) ? 3 : 4;
-    return sizeof(T) == 8 ? ((F & F_UV) ? 2 : 3) : 4;
+    return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
 #endif
 }
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
