@@ -25,9 +25,12 @@
 // tests/hostsim can count traversal events (node classifications, exact fallbacks, leaf tests); a no-op on the device
 #if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
 extern "C" unsigned long long g_sim_counters[8];
+extern "C" unsigned long long g_sim_walk_hist[64];  // walks by number of node classifications, bins of 8
 #define RT_SIM_COUNT(i) (g_sim_counters[i]++)
+#define RT_SIM_WALK(n0) (g_sim_walk_hist[(g_sim_counters[0] - (n0)) / 8 > 63 ? 63 : (g_sim_counters[0] - (n0)) / 8]++)
 #else
 #define RT_SIM_COUNT(i) ((void)0)
+#define RT_SIM_WALK(n0) ((void)0)
 #endif
 
 // Profiling build (-DRT_PHASE_CLOCK, tools/build_ab.py): per-wave cycle and active-lane sums per phase of the
@@ -545,6 +548,9 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
     int i = w.i;
     const int end = w.end;
     T closest = w.closest;
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+    const unsigned long long sim_n0 = g_sim_counters[0];
+#endif
     for (;;) {
         int prim = -1;
         bool undecided = false;
@@ -596,6 +602,9 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
     }
     w.i = i;
     w.closest = closest;
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+    RT_SIM_WALK(sim_n0);
+#endif
 }
 
 // Geometry of an instance: one primitive, or a complete BVH walk.

@@ -72,7 +72,7 @@ void frame(const rt::DScene<T>& sc, const rt::RenderArgs& a, double* accum, uint
 }  // namespace
 
 #ifdef RT_SIM_COUNTERS
-extern "C" { unsigned long long g_sim_counters[8] = {0}; }
+extern "C" { unsigned long long g_sim_counters[8] = {0}; unsigned long long g_sim_walk_hist[64] = {0}; }
 #endif
 extern "C" {
 const char* sim_last_error() { return rt::pack_error().c_str(); }

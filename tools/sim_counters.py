@@ -44,3 +44,11 @@ for precision in ("f64", "f32"):
     print(f"{name} {W}x{H}@{spp} {precision}: {casts.value} casts")
     for i, nm in enumerate(names):
         print(f"  {nm:34s} {ctr[i] / n:9.3f} per cast")
+    hist = np.array(list((C.c_ulonglong * 64).in_dll(L, "g_sim_walk_hist")), dtype=np.float64)
+    for i in range(64):
+        (C.c_ulonglong * 64).in_dll(L, "g_sim_walk_hist")[i] = 0
+    if hist.sum() > 0:
+        cdf = np.cumsum(hist) / hist.sum()
+        mean = (hist * (np.arange(64) * 8 + 4)).sum() / hist.sum()
+        pct = {q: int(np.searchsorted(cdf, q) * 8 + 8) for q in (0.5, 0.75, 0.9, 0.98, 0.999)}
+        print(f"  BVH walks: {int(hist.sum())}, node classifications per walk: mean {mean:.1f}, percentiles (upper bin edge) {pct}")
