@@ -117,7 +117,7 @@ template <class T> struct DScene {
     const DPerlin<T>* perlin_lds;     // perlins [0, n_perlin_lds) staged in LDS by the render kernel (else n_perlin_lds = 0)
     uint32_t n_perlins, n_perlin_lds;
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
-    uint32_t n_world, n_lights;
+    uint32_t n_world, n_lights, n_materials;
     T background[3];
     DCamera<T> cam;
 };

@@ -332,6 +332,7 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     out.n_perlin_lds = 0;
     out.perlin_lds = nullptr;
     out.n_world = d->n_world;
+    out.n_materials = d->n_materials;
     out.n_lights = d->n_lights;
     for (int k = 0; k < 3; k++) out.background[k] = (T)d->background[k];
     const RtCamera& c = d->camera;

@@ -38,21 +38,23 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_en
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin_tables() {
     return (F & F_NOISE) ? ((F & F_BVH) ? 1u : 2u) : 0u;
 }
-// The block-sorted kernel waits at two barriers per iteration: it wants more resident waves than the wave-level
-// kernel even at the price of a few spills (f64 Cornell: +14 % at 4 waves/SIMD vs 3; its 39.5 KB of LDS admit 4
-// blocks per CU).  The figure must be one the kernel's LDS admits — the compiler drops an unreachable request
+// The block-sorted kernel waits at two barriers per iteration: it wants resident waves even at the price of a few
+// spills.  Measured on cornell_box / cornell_smoke (profiles/): f64 best at 4 waves/SIMD (128 registers,
+// 44 B of spills; at 5 waves 96 registers spill 176 B and lose 15 %), f32 best at 7 (73 registers: 4 -> 7 waves
+// +17 % / +31 %).  The figure must be one the kernel's LDS admits — the compiler drops an unreachable request
 // altogether and then allocates up to 256 registers.
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds_bytes() {
-    return ((F & F_UV) ? 15u : 13u) * 256u * (uint32_t)sizeof(T) + 7u * 1024u + 6144u + 68u +
+    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * 256u * (uint32_t)sizeof(T) + 6u * 1024u + 1536u + 68u +
            lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
 }
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
-#ifdef RT_WAVES_PER_SIMD_SORTED
-    return RT_WAVES_PER_SIMD_SORTED;
+#ifdef RT_SORTED_MAX_WAVES
+    constexpr uint32_t most = RT_SORTED_MAX_WAVES;
 #else
-    // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
-    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (163840u / sorted_lds_bytes<T, F>() >= 4u ? 4 : (int)(163840u / sorted_lds_bytes<T, F>()));
+    constexpr uint32_t most = sizeof(T) == 8 ? 4u : 7u;
 #endif
+    // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
+    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (163840u / sorted_lds_bytes<T, F>() >= most ? (int)most : (int)(163840u / sorted_lds_bytes<T, F>()));
 }
 }  // namespace rt
 
