@@ -6,8 +6,9 @@
       bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE configs[1]): cornell_box, 1024x1024, mixture-PDF light importance sampling, depth 50.
-A STEP is one rt_render launch over the whole frame adding `--spp-per-step` (256) samples to every pixel;
-the default K = 4 steps are exactly the 1024 spp of the config.  Scene and accumulation buffer are
+A STEP is one rt_render launch over the whole frame adding `--spp-per-step` samples to every pixel; the default
+is the config's 1024 spp in ONE launch, so a step is one complete render of the config (K = 4 renders by default;
+shorter launches pay the drain of each tile's job list more often: 64 spp/launch 2690, 256: 2990, 1024: 3075 Msamples/s).  Scene and accumulation buffer are
 resident in HBM before the timed region.  With N > 1 every rank renders its own disjoint sample indices
 of the full frame (weak scaling: per-GPU work fixed) and the float accumulation buffers are summed by
 ONE RCCL all-reduce inside the timed region (SURVEY §8 e).
@@ -58,7 +59,7 @@ def parse():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--spp-per-step", type=int, default=1024)
     ap.add_argument("--precision", default="f64", choices=("f64", "f32"))
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
