@@ -241,26 +241,27 @@ def test_wave_kernel_and_sorted_kernel_agree(name, scenes):
     assert abs(int(sa[1]) - cnt["casts"]) <= 0.002 * cnt["casts"]
 
 
-@pytest.mark.parametrize("name,W,H,spp", (("random_scene", 40, 24, 32), ("cornell_box", 33, 18, 24), ("final_scene", 24, 24, 8)))
+@pytest.mark.parametrize("name,W,H,spp", (("random_scene", 40, 24, 32), ("cornell_box", 33, 18, 96), ("final_scene", 24, 24, 8)))
 def test_persistent_kernel_sample_chunks(name, W, H, spp, scenes):
-    # small frame, many samples: the persistent kernel splits every 8x8 tile's samples into chunks that different
-    # waves render concurrently and add with float atomics.  The frame must still be the oracle's, every sample
-    # counted once.
+    # small frame, many samples: both render kernels split every 8x8 tile's samples into chunks that different
+    # waves / blocks render concurrently and add with float atomics.  The frame must still be the oracle's, every
+    # sample counted once.
     ds = scenes(name, W / H)
-    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
-    st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
-    ds.render_into(a, 3, spp, precision="f64", stats=st, no_sort=True)
     ref, cnt = OracleScene(name, W / H).render(W, H, 3, spp, threads=8)
-    got = a.cpu().numpy().astype(np.float64)
-    close = (np.abs(got - ref) <= 4e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
-    assert close.mean() >= 0.995, (name, close.mean())
-    assert st[0].item() + st[3].item() == W * H * spp
-    assert abs(int(st[1]) - cnt["casts"]) <= 0.003 * cnt["casts"] + 2
-    # two launches of half the samples add up to the same frame
-    b = torch.zeros_like(a)
-    ds.render_into(b, 3, spp // 2, precision="f64", no_sort=True)
-    ds.render_into(b, 3 + spp // 2, spp - spp // 2, precision="f64", no_sort=True)
-    assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
+    for no_sort in (True, False):  # (False selects the block-sorted kernel for cornell_box only)
+        a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(a, 3, spp, precision="f64", stats=st, no_sort=no_sort)
+        got = a.cpu().numpy().astype(np.float64)
+        close = (np.abs(got - ref) <= 4e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995, (name, no_sort, close.mean())
+        assert st[0].item() + st[3].item() == W * H * spp
+        assert abs(int(st[1]) - cnt["casts"]) <= 0.003 * cnt["casts"] + 2
+        # two launches of half the samples add up to the same frame
+        b = torch.zeros_like(a)
+        ds.render_into(b, 3, spp // 2, precision="f64", no_sort=no_sort)
+        ds.render_into(b, 3 + spp // 2, spp - spp // 2, precision="f64", no_sort=no_sort)
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
 
 
 # ---- BASELINE sizes: properties that need no oracle run ------------------------------------------------
