@@ -43,8 +43,11 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin
 // 44 B of spills; at 5 waves 96 registers spill 176 B and lose 15 %), f32 best at 7 (73 registers: 4 -> 7 waves
 // +17 % / +31 %).  The figure must be one the kernel's LDS admits — the compiler drops an unreachable request
 // altogether and then allocates up to 256 registers.
+#ifndef RT_SORT_TILE_H
+#define RT_SORT_TILE_H 8  // the sorted kernel's tile is 8 pixels wide and this high (rt_kernels.inc)
+#endif
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds_bytes() {
-    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * 256u * (uint32_t)sizeof(T) + 6u * 1024u + 1536u + 68u +
+    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * 256u * (uint32_t)sizeof(T) + 6u * 1024u + 192u * RT_SORT_TILE_H + 68u +
            lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
 }
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
