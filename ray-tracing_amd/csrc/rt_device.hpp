@@ -477,6 +477,42 @@ __device__ inline void ray_consts(RayR<R>& r, V3<T> o, V3<T> d, T t_min, R B, R 
     widen<R>((R)t_min, r.tmin_lo, r.tmin_hi);
 }
 
+// First level in its cheapest form.  Per axis the four values (bound - o)/d -+ e for the two bounds come from one
+// multiply-add each, a = bound * (1/d) + (-o * (1/d) -+ e): the margin is folded into the addend, and with it the
+// four interval ends lo-e, lo+e, hi-e, hi+e are plain min / max of those.  The rounding of this form (product,
+// addend, final sum: each < 2^-24 (|o| + B)|1/d|) stays inside the same e = 2^-18 (|o| + B)|1/d| as before.
+// A ray whose constants are not all finite (axis-parallel: 1/d = inf; overflow) is marked `bad`: all its nodes are
+// undecided and go to the second level / the exact test.  With finite constants and finite boxes no NaN can arise
+// per node (an overflowing product gives +-inf, never inf - inf), so there is no per-node NaN test.
+struct RayF { float ix, iy, iz, kpx, kpy, kpz, kmx, kmy, kmz, tmin_lo, tmin_hi; bool bad; };
+template <class T> __device__ inline void ray_consts_f(RayF& r, V3<T> o, V3<T> d, T t_min, float B) {
+    const float rel = 3.814697265625e-06f;  // 2^-18
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    r.ix = 1.0f / (float)d.x; r.iy = 1.0f / (float)d.y; r.iz = 1.0f / (float)d.z;
+    const float ex = (fabsf(ox) + B + 1e-30f) * rel * fabsf(r.ix);
+    const float ey = (fabsf(oy) + B + 1e-30f) * rel * fabsf(r.iy);
+    const float ez = (fabsf(oz) + B + 1e-30f) * rel * fabsf(r.iz);
+    const float cx = -ox * r.ix, cy = -oy * r.iy, cz = -oz * r.iz;
+    r.kpx = cx + ex; r.kmx = cx - ex;
+    r.kpy = cy + ey; r.kmy = cy - ey;
+    r.kpz = cz + ez; r.kmz = cz - ez;
+    const float chk = (r.ix - r.ix) + (r.iy - r.iy) + (r.iz - r.iz) + (r.kpx - r.kpx) + (r.kpy - r.kpy) + (r.kpz - r.kpz) +
+                      (r.kmx - r.kmx) + (r.kmy - r.kmy) + (r.kmz - r.kmz);  // 0 iff all nine are finite
+    r.bad = !(chk == 0.0f);
+    widen<float>((float)t_min, r.tmin_lo, r.tmin_hi);
+}
+__device__ inline int aabb_classify_f(const float* mn, const float* mx, const RayF& r, float tmax_lo, float tmax_hi) {
+    const float x1p = fmaf(mn[0], r.ix, r.kpx), x2p = fmaf(mx[0], r.ix, r.kpx), x1m = fmaf(mn[0], r.ix, r.kmx), x2m = fmaf(mx[0], r.ix, r.kmx);
+    const float y1p = fmaf(mn[1], r.iy, r.kpy), y2p = fmaf(mx[1], r.iy, r.kpy), y1m = fmaf(mn[1], r.iy, r.kmy), y2m = fmaf(mx[1], r.iy, r.kmy);
+    const float z1p = fmaf(mn[2], r.iz, r.kpz), z2p = fmaf(mx[2], r.iz, r.kpz), z1m = fmaf(mn[2], r.iz, r.kmz), z2m = fmaf(mx[2], r.iz, r.kmz);
+    const float in_lo = fmaxf(fmaxf(fminf(x1p, x2p), fminf(y1p, y2p)), fmaxf(fminf(z1p, z2p), r.tmin_hi));   // lo + e
+    const float in_hi = fminf(fminf(fmaxf(x1m, x2m), fmaxf(y1m, y2m)), fminf(fmaxf(z1m, z2m), tmax_lo));     // hi - e
+    const float out_lo = fmaxf(fmaxf(fminf(x1m, x2m), fminf(y1m, y2m)), fmaxf(fminf(z1m, z2m), r.tmin_lo));  // lo - e
+    const float out_hi = fminf(fminf(fmaxf(x1p, x2p), fmaxf(y1p, y2p)), fminf(fmaxf(z1p, z2p), tmax_hi));    // hi + e
+    if (r.bad) return 2;
+    return in_hi - in_lo > 0.0f ? 1 : (out_hi - out_lo < 0.0f ? 0 : 2);
+}
+
 // Entry i of the table staged in LDS.  The generic pointer is narrowed to the LDS address space by hand
 // (its low 32 bits are the LDS offset): the optimiser cannot infer it through DScene, and a flat load
 // would wait on both memory counters.
@@ -503,7 +539,7 @@ template <class T> struct Walk {
     T closest, t_min;
     bool any, leaf_cull;
     int prim, side;
-    RayR<float> r;     // per-ray constants of the first-level box classification
+    RayF r;            // per-ray constants of the first-level box classification
     RayR<T> r2;        // second level (f64 mode only)
 };
 template <class T, uint32_t F>
@@ -522,7 +558,7 @@ __device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T
         B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
         B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
     }
-    ray_consts<float, T>(w.r, o, d, t_min, B, 3.814697265625e-06f);  // 2^-18 (|o| + B): f32 rounding of o, box, products
+    ray_consts_f<T>(w.r, o, d, t_min, B);  // 2^-18 (|o| + B)|1/d|: f32 rounding of o, box, products
     if (sizeof(T) == 8) {
         ray_consts<T, T>(w.r2, o, d, t_min, (T)B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
     }
@@ -562,7 +598,7 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
         while (i != end) {
             if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.bvh_lite[i];
             prim = e.prim;
-            const int c = aabb_classify<float, float>(e.mn, e.mx, w.r, tmax_lo, tmax_hi);
+            const int c = aabb_classify_f(e.mn, e.mx, w.r, tmax_lo, tmax_hi);
             RT_SIM_COUNT(0);
             if (prim >= 0) {
                 // a leaf the first level cannot rule out is tested (its box only serves to skip certain misses)
