@@ -264,6 +264,33 @@ def test_persistent_kernel_sample_chunks(name, W, H, spp, scenes):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
 
 
+def test_concurrent_launches_on_two_streams(scenes):
+    # rt_render is asynchronous on the caller's stream; two launches of ONE scene handle in flight on different streams
+    # draw their jobs from different counters of the handle's ring and must not disturb each other
+    ds = scenes("random_scene", 1.5)
+    W, H, spp = 96, 64, 24
+    seq = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    ds.render_into(seq[0], 0, spp, precision="f64")
+    ds.render_into(seq[1], spp, spp, precision="f64")
+    torch.cuda.synchronize()
+    con = [torch.zeros_like(seq[0]) for _ in range(2)]
+    st = [torch.zeros(4, dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                if rep == 0:
+                    ds.render_into(con[k], k * spp, spp, precision="f64", stats=st[k])
+                else:  # keep both streams busy so that the launches really overlap
+                    scratch = torch.zeros_like(con[k])
+                    ds.render_into(scratch, (2 + rep) * spp, spp, precision="f64")
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.allclose(con[k], seq[k], rtol=2e-6, atol=1e-6)
+        assert st[k][0].item() == W * H * spp
+
+
 # ---- BASELINE sizes: properties that need no oracle run ------------------------------------------------
 def test_full_size_cornell_properties(scenes, golden_dir):
     # cornell_box 1024x1024 (BASELINE configs[1]).  The oracle cannot render this in test time; what must hold at
