@@ -245,7 +245,7 @@ class FlatScene:
 
 def scene_from_json(text, aspect_ratio=None, background=(0.0, 0.0, 0.0)):
     """The reference's JSON scene vocabulary (codegen/src/scenes_file.rs:19-152; data in codegen/data/*.json):
-    objects: ObjectList{items[]} | Sphere{center,radius,material} | BVHNode{left,right[,bounding_box]};
+    objects: ObjectList{items[]} (nested lists allowed at list level) | Sphere{center,radius,material} | BVHNode{left,right[,bounding_box]};
     materials Lambertian{albedo: texture} | Metal{albedo,fuzz} | Dielectric{ref_idx} | DiffuseLight{emit: texture};
     textures SolidColor{color} | CheckerTexture{odd,even}; camera{lookfrom,lookat,vup,vfov,aspect_ratio,aperture,focus_dist}.
     As in scenes_file.rs: a BVHNode's box is the surrounding box of its children's boxes over (0,1)
@@ -294,11 +294,17 @@ def scene_from_json(text, aspect_ratio=None, background=(0.0, 0.0, 0.0)):
             return ("node", me)
         raise ValueError("object type " + o["type"])
 
-    root = j["objects"]
-    items = root["items"] if root["type"] == "ObjectList" else [root]
-    for o in items:
+    def add(o):
+        # An ObjectList inside the world list scans its items in order with the caller's closest-so-far as t_max
+        # (src/objects.rs:38-48), which is the scan of the items spliced into the outer list: flattened in place.
+        if o["type"] == "ObjectList":
+            for x in o["items"]:
+                add(x)
+            return
         k, i = geom(o)
         fs.add_world(i, bvh=(k == "node"))
+
+    add(j["objects"])
     c = j["camera"]
     fs.camera(vec(c["lookfrom"]), vec(c["lookat"]), vec(c["vup"]), float(c["vfov"]),
               float(aspect_ratio if aspect_ratio is not None else c["aspect_ratio"]), float(c["aperture"]), float(c["focus_dist"]), 0.0, 1.0)

@@ -61,19 +61,29 @@ def test_flat_scene_dict_roundtrip():
     assert list(a.camera.horizontal) == list(b.camera.horizontal)
 
 
+JSON_SCENES = {  # reference file -> (fixture, prims, BVH nodes, world list entries)
+    "scene_10": ("json_scene10", 25, 19, 6),
+    "scene_200_no_bvh": ("json_scene_200_no_bvh", 405, 0, 405),   # a nested ObjectList of 400 spheres: spliced in place
+    "scene_500": ("json_scene_500", 1005, 999, 6),
+}
+
+
 @pytest.mark.skipif(not os.path.exists(REF_JSON), reason="reference JSON scene data not present")
-def test_reference_json_scene_loads_and_matches_fixture(sim):
-    # codegen/data/scene_10.json: 25 spheres, 19 BVHNode records with an explicit topology.  The committed fixture
-    # (tools/make_json_fixture.py) holds the flat form derived from it and the oracle's probe of it.
-    fs = flat.scene_from_json(open(REF_JSON).read())
+@pytest.mark.parametrize("name", sorted(JSON_SCENES))
+def test_reference_json_scene_loads_and_matches_fixture(name):
+    # codegen/data/*.json: spheres, explicit BVHNode topologies, nested lists.  The committed fixtures
+    # (tools/make_json_fixture.py) hold the flat form derived from each file and the oracle's probe of it.
+    fixture, n_prims, n_nodes, n_world = JSON_SCENES[name]
+    fs = flat.scene_from_json(open(os.path.join(os.path.dirname(REF_JSON), name + ".json")).read())
     d = fs.desc()
-    assert d.n_prims == 25 and d.bvh.n_nodes == 19 and d.n_world == 6 and d.n_lights == 0
-    fx = np.load(os.path.join(GOLDEN, "json_scene10.npz"))
+    assert d.n_prims == n_prims and d.bvh.n_nodes == n_nodes and d.n_world == n_world and d.n_lights == 0
+    fx = np.load(os.path.join(GOLDEN, fixture + ".npz"))
     assert json.loads(str(fx["flat_scene"])) == json.loads(json.dumps(fs.to_dict()))
 
 
-def test_json_fixture_sim_equals_oracle(sim):
-    fx = np.load(os.path.join(GOLDEN, "json_scene10.npz"))
+@pytest.mark.parametrize("name", sorted(JSON_SCENES))
+def test_json_fixture_sim_equals_oracle(name, sim):
+    fx = np.load(os.path.join(GOLDEN, JSON_SCENES[name][0] + ".npz"))
     fs = flat.FlatScene.from_dict(json.loads(str(fx["flat_scene"])))
     host = rt.FlatHostScene(fs)
     oc = OracleScene.from_desc(host.desc_ptr)
@@ -82,5 +92,6 @@ def test_json_fixture_sim_equals_oracle(sim):
     sc = SimScene.from_host(sim, host)
     ids2, ts2 = sc.primary(64, 64, 0.0, 0.5)
     assert np.array_equal(ids2, fx["ids"]) and np.array_equal(ts2, fx["t"])         # device templates, bit-exact
-    got, _ = sc.samples(32, 32, 0, 11, 0, 32)
+    px, py = (int(v) for v in fx["pixel"])
+    got, _ = sc.samples(32, 32, px, py, 0, 32)
     assert np.allclose(got, fx["samples"], rtol=RAD_RTOL, atol=0)

@@ -373,18 +373,30 @@ def test_random_flat_scene_gpu_equals_oracle(seed, gpu):
         ds.close()
 
 
-def test_json_scene_fixture_gpu(gpu, golden_dir):
-    # the reference's codegen/data/scene_10.json in flat form (tests/golden/json_scene10.npz, tools/make_json_fixture.py)
+@pytest.mark.parametrize("fixture", ("json_scene10", "json_scene_200_no_bvh", "json_scene_500"))
+def test_json_scene_fixture_gpu(fixture, gpu, golden_dir):
+    # the reference's codegen/data/*.json in flat form (tests/golden/json_*.npz, tools/make_json_fixture.py):
+    # 25 spheres + 19 nodes; 405 spheres in a plain list (no BVH: a 405-entry world scan); 1005 spheres + 999 nodes
     import json
     from ray_tracing_amd import flat
-    fx = np.load(os.path.join(golden_dir, "json_scene10.npz"))
+    fx = np.load(os.path.join(golden_dir, fixture + ".npz"))
     host = rt.FlatHostScene(flat.FlatScene.from_dict(json.loads(str(fx["flat_scene"]))))
     ds = rt.DeviceScene(host, 0)
     try:
         ids, ts = ds.trace_primary(64, 64, 0.0, 0.5, "f64")
         assert np.array_equal(ids.cpu().numpy(), fx["ids"]) and np.array_equal(ts.cpu().numpy(), fx["t"])
-        got = ds.sample_pixel(32, 32, 0, 11, 0, 32, precision="f64").cpu().numpy()
+        px, py = (int(v) for v in fx["pixel"])
+        got = ds.sample_pixel(32, 32, px, py, 0, 32, precision="f64").cpu().numpy()
         ref = fx["samples"]
         assert (np.abs(got - ref) <= SAMPLE_RTOL * np.maximum(np.abs(ref), 1.0)).all(axis=1).sum() >= 31
+        # a small frame through the render kernel against the oracle rebuilt from the same description
+        oc = OracleScene.from_desc(host.desc_ptr)
+        W, H, spp = 40, 30, 4
+        ref_f, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        close = (np.abs(acc.cpu().numpy() - ref_f) <= 2e-6 * np.maximum(np.abs(ref_f), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
