@@ -173,7 +173,7 @@ def test_spp_shards_add_up(scenes):
 
 def test_ragged_frame_and_edge_cases(scenes):
     ds = scenes("cornell_box")
-    # width/height not multiples of the 16x16 tile; the pixels outside must not be touched
+    # width/height not multiples of the 8x8 tiles; the pixels outside must not be touched
     W, H = 37, 19
     buf = torch.full((H + 1, W, 3), -1.0, dtype=torch.float32, device="cuda:0")
     acc = buf[:H]
@@ -225,7 +225,7 @@ def test_wave_kernel_and_sorted_kernel_agree(name, scenes):
     # light-sampling scenes without BVH instances (the Cornell ones) run the block-sorted kernel by default;
     # RT_RENDER_NO_SORT selects the persistent wave-level kernel that every other scene uses.  Same keyed
     # samples -> same sums (up to the order of the additions per pixel), and both equal the oracle's frame.
-    W, H, spp = 50, 35, 5  # ragged against the 16x16 tiles
+    W, H, spp = 50, 35, 5  # ragged against the 8x8 tiles
     ds = scenes(name)
     a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
     b = torch.zeros_like(a)
