@@ -51,8 +51,9 @@ def main(argv=None):
     stats = torch.zeros(4, dtype=torch.int64, device=f"cuda:{local}")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    spp_done = a.spp
     if a.checkpoint:
-        acc, _ = rt.render_progressive(ds, a.width, a.height, a.spp, a.pass_spp or max(1, a.spp // 8), seed=a.seed, max_depth=a.depth,
+        acc, spp_done = rt.render_progressive(ds, a.width, a.height, a.spp, a.pass_spp or max(1, a.spp // 8), seed=a.seed, max_depth=a.depth,
                                        precision=a.precision, spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
                                        all_reduce=dist.all_reduce if world > 1 else None, stats=stats, checkpoint=a.checkpoint,
                                        resume=a.resume, scene_name=a.scene)
@@ -65,7 +66,7 @@ def main(argv=None):
     if world > 1:
         dist.all_reduce(stats)
     if rank == 0:
-        rgb = rt.resolve(acc, a.spp)
+        rgb = rt.resolve(acc, spp_done)  # the sums hold spp_done samples per pixel
         if a.out:
             os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
             rt.write_png(a.out, rgb)

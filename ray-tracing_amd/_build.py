@@ -22,6 +22,7 @@ UNITS = [
     ("rt_kernels_f64.hip", ["-O3", "-ffp-contract=off"]),
     ("rt_kernels_f32.hip", ["-O3", "-ffp-contract=fast"]),
     ("rt_hip.hip", ["-O2"]),
+    ("rt_exchange.hip", ["-O2"]),  # RCCL all-reduce entry points; RCCL itself is bound at run time (dlopen)
 ]
 HOST_SRC = ["scene_api.cpp", "scenes.cpp", "flatten.cpp", "jpeg.cpp", "capi.cpp"]
 HOST_FLAGS = ["-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-shared"]
@@ -57,7 +58,7 @@ def build_hip(force=False, defines=(), out=None, tag="", f64_flags=()):
             _run([HIPCC] + COMMON + flags + extra + ["-D" + d for d in defines] + ["-c", s, "-o", o])
         objs.append(o)
     if force or _newer(lib_out, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_out] + objs)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_out] + objs + ["-ldl"])
     return lib_out
 
 

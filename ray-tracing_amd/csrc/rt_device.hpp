@@ -461,7 +461,12 @@ __device__ inline int aabb_classify(const BoxT* mn, const BoxT* mx, const RayR<R
     if (nan) return 2;
     return in_hi - in_lo > R(0) ? 1 : (out_hi - out_lo < R(0) ? 0 : 2);
 }
-// t widened by one part in 2^20 either way (covers its rounding to f32; harmless in f64)
+// T -> f32, saturating at +-FLT_MAX: the search ranges start at +-f64::MAX (ray_tracing.rs:22, objects.rs:530), which is
+// outside f32 (the plain cast is undefined in C++ and gives inf, whose widened ends would be inf - inf = NaN)
+__device__ inline float to_f32_sat(double t) { return (float)(t > 3.4028234663852886e38 ? 3.4028234663852886e38 : (t < -3.4028234663852886e38 ? -3.4028234663852886e38 : t)); }
+__device__ inline float to_f32_sat(float t) { return t; }
+// t widened by one part in 2^20 either way (covers its rounding to f32; harmless in f64).  At +-FLT_MAX the outer end
+// overflows to +-inf, which is the right bound.
 template <class R> __device__ inline void widen(R t, R& lo, R& hi) {
     const R w = (t < R(0) ? -t : t) * R(9.5367431640625e-07);
     lo = t - w; hi = t + w;
@@ -499,7 +504,7 @@ template <class T> __device__ inline void ray_consts_f(RayF& r, V3<T> o, V3<T> d
     const float chk = (r.ix - r.ix) + (r.iy - r.iy) + (r.iz - r.iz) + (r.kpx - r.kpx) + (r.kpy - r.kpy) + (r.kpz - r.kpz) +
                       (r.kmx - r.kmx) + (r.kmy - r.kmy) + (r.kmz - r.kmz);  // 0 iff all nine are finite
     r.bad = !(chk == 0.0f);
-    widen<float>((float)t_min, r.tmin_lo, r.tmin_hi);
+    widen<float>(to_f32_sat(t_min), r.tmin_lo, r.tmin_hi);
 }
 __device__ inline int aabb_classify_f(const float* mn, const float* mx, const RayF& r, float tmax_lo, float tmax_hi) {
     const float x1p = fmaf(mn[0], r.ix, r.kpx), x2p = fmaf(mx[0], r.ix, r.kpx), x1m = fmaf(mn[0], r.ix, r.kmx), x2m = fmaf(mx[0], r.ix, r.kmx);
@@ -591,7 +596,7 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
         int prim = -1;
         bool undecided = false;
         float tmax_lo, tmax_hi;
-        widen<float>((float)closest, tmax_lo, tmax_hi);
+        widen<float>(to_f32_sat(closest), tmax_lo, tmax_hi);
         RT_PCB();
         DBvhLite e;
         e.skip = end;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -31,11 +33,19 @@ struct RtScene {
     std::vector<void*> allocs;
     uint32_t n_prims = 0;
     // job counters of the persistent render kernel: a ring, one word per launch, so that launches queued on
-    // different streams do not share one (64 launches in flight per scene at most)
+    // different streams do not share one.  A slot is reused after kCounters further launches: if its previous
+    // launch went to ANOTHER stream, the new launch first waits (on the device, hipStreamWaitEvent) for the event
+    // recorded behind that launch; on the same stream, stream order already separates the two.
     static constexpr uint32_t kCounters = 64;
     uint32_t* d_counters = nullptr;
     uint32_t next_counter = 0;
+    hipEvent_t slot_event[kCounters] = {};
+    hipStream_t slot_stream[kCounters] = {};
+    bool slot_recorded[kCounters] = {};
     uint32_t cu_count = 0;
+    // rt_render_rgb8: the float accumulation buffer between the render and the resolve kernel (grown on demand)
+    float* d_work = nullptr;
+    uint64_t work_floats = 0;
 };
 
 namespace {
@@ -102,13 +112,11 @@ int rt_init(int device) {
 
 const char* rt_describe(void) { return g_desc.c_str(); }
 
-int rt_scene_create(const RtSceneDesc* desc, RtScene** out) {
-    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
-    *out = nullptr;
+static int scene_create(const RtSceneDesc* desc, RtScene*& sc, RtScene** out) {
     int rc = rt::validate(desc);
     if (rc) return rc;
-    RtScene* sc = new RtScene();
-    if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; return fail(RT_ERR_NO_DEVICE, "no current HIP device (call rt_init)"); }
+    sc = new RtScene();
+    if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; sc = nullptr; return fail(RT_ERR_NO_DEVICE, "no current HIP device (call rt_init)"); }
     sc->n_prims = desc->n_prims;
     sc->features = rt::scene_features(desc);
     // images: texel rasters + descriptor table
@@ -137,14 +145,32 @@ int rt_scene_create(const RtSceneDesc* desc, RtScene** out) {
             sc->cu_count = (uint32_t)prop.multiProcessorCount;
         }
     }
-    if (rc != RT_OK) { rt_scene_destroy(sc); return rc; }
+    if (rc != RT_OK) { rt_scene_destroy(sc); sc = nullptr; return rc; }
     *out = sc;
     return RT_OK;
+}
+
+int rt_scene_create(const RtSceneDesc* desc, RtScene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    RtScene* sc = nullptr;
+    try {  // nothing may unwind across the C boundary (host vectors of a huge description can throw bad_alloc)
+        return scene_create(desc, sc, out);
+    } catch (const std::bad_alloc&) {
+        if (sc) rt_scene_destroy(sc);
+        return fail(RT_ERR_INVALID, "out of host memory while packing the scene description");
+    } catch (const std::exception& e) {
+        if (sc) rt_scene_destroy(sc);
+        return fail(RT_ERR_INVALID, std::string("scene description rejected: ") + e.what());
+    }
 }
 
 int rt_scene_destroy(RtScene* scene) {
     if (!scene) return RT_OK;
     for (void* p : scene->allocs) (void)hipFree(p);
+    if (scene->d_work) (void)hipFree(scene->d_work);
+    for (hipEvent_t e : scene->slot_event)
+        if (e) (void)hipEventDestroy(e);
     delete scene;
     return RT_OK;
 }
@@ -173,6 +199,39 @@ static int make_args(const RtRenderParams* p, rt::RenderArgs& a) {
     return RT_OK;
 }
 
+// One render launch with the job-counter word the caller chose (a slot of the scene's ring).
+static int render_launch(RtScene* scene, const RtRenderParams* params, const rt::RenderArgs& a, uint32_t* d_counter, float* d_accum,
+                         uint64_t* d_stats, hipStream_t stream) {
+    const rt::LaunchCtx ctx{d_counter, scene->cu_count};
+    const bool no_sort = (params->flags & RT_RENDER_NO_SORT) != 0;
+    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, stream));
+    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, stream));
+    else return fail(RT_ERR_INVALID, "unknown precision");
+    return RT_OK;
+}
+
+// Take the next slot of the scene's job-counter ring for a launch on `stream` (see RtScene).
+static int ring_acquire(RtScene* scene, hipStream_t stream, uint32_t& slot, bool& capturing) {
+    slot = scene->next_counter++ % RtScene::kCounters;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (hipGetLastError() != hipSuccess) {}  // (a legacy-stream query during another stream's capture only sets the sticky error)
+    if (scene->slot_recorded[slot] && scene->slot_stream[slot] != stream && !capturing)
+        HIP_TRY(hipStreamWaitEvent(stream, scene->slot_event[slot], 0));
+    return RT_OK;
+}
+static int ring_release(RtScene* scene, hipStream_t stream, uint32_t slot, bool capturing) {
+    if (capturing) {  // events recorded inside a capture cannot guard launches outside it: the slot is left unguarded
+        scene->slot_recorded[slot] = false;
+        return RT_OK;
+    }
+    if (!scene->slot_event[slot]) HIP_TRY(hipEventCreateWithFlags(&scene->slot_event[slot], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(scene->slot_event[slot], stream));
+    scene->slot_stream[slot] = stream;
+    scene->slot_recorded[slot] = true;
+    return RT_OK;
+}
+
 int rt_render(RtScene* scene, const RtRenderParams* params, float* d_accum, uint64_t* d_stats, void* stream) {
     int rc = check_scene(scene);
     if (rc) return rc;
@@ -180,11 +239,35 @@ int rt_render(RtScene* scene, const RtRenderParams* params, float* d_accum, uint
     if ((rc = make_args(params, a))) return rc;
     if (!d_accum) return fail(RT_ERR_INVALID, "d_accum is NULL");
     if (a.spp_count == 0) return RT_OK;
-    const rt::LaunchCtx ctx{scene->d_counters + (scene->next_counter++ % RtScene::kCounters), scene->cu_count};
-    const bool no_sort = (params->flags & RT_RENDER_NO_SORT) != 0;
-    if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
-    else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, (hipStream_t)stream));
-    else return fail(RT_ERR_INVALID, "unknown precision");
+    uint32_t slot; bool capturing;
+    if ((rc = ring_acquire(scene, (hipStream_t)stream, slot, capturing))) return rc;
+    if ((rc = render_launch(scene, params, a, scene->d_counters + slot, d_accum, d_stats, (hipStream_t)stream))) return rc;
+    return ring_release(scene, (hipStream_t)stream, slot, capturing);
+}
+
+// ray_tracing.rs:95-118 as ONE call: sample loop + tonemap, 8-bit image out.  The float sums between the two kernels
+// live in a work buffer of the scene handle, (re)allocated here when the frame outgrows it.
+int rt_render_rgb8(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb, uint64_t* d_stats, void* stream) {
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    rt::RenderArgs a;
+    if ((rc = make_args(params, a))) return rc;
+    if (!d_rgb) return fail(RT_ERR_INVALID, "d_rgb is NULL");
+    if (a.spp_count == 0) return fail(RT_ERR_INVALID, "spp_count must be > 0 (the image is the mean of the samples)");
+    const uint64_t floats = (uint64_t)a.width * a.height * 3u;
+    if (floats > 0xffffffffull) return fail(RT_ERR_INVALID, "frame too large for the resolve kernel (width*height*3 must fit 32 bits)");
+    if (scene->work_floats < floats) {
+        if (scene->d_work) HIP_TRY(hipFree(scene->d_work));  // hipFree waits for the device: no launch still reads it
+        scene->d_work = nullptr; scene->work_floats = 0;
+        HIP_TRY(hipMalloc((void**)&scene->d_work, floats * sizeof(float)));
+        scene->work_floats = floats;
+    }
+    HIP_TRY(hipMemsetAsync(scene->d_work, 0, floats * sizeof(float), (hipStream_t)stream));
+    uint32_t slot; bool capturing;
+    if ((rc = ring_acquire(scene, (hipStream_t)stream, slot, capturing))) return rc;
+    if ((rc = render_launch(scene, params, a, scene->d_counters + slot, scene->d_work, d_stats, (hipStream_t)stream))) return rc;
+    if ((rc = ring_release(scene, (hipStream_t)stream, slot, capturing))) return rc;
+    HIP_TRY(rt::launch_resolve(scene->d_work, a.width, a.height, a.spp_count, d_rgb, (hipStream_t)stream));
     return RT_OK;
 }
 

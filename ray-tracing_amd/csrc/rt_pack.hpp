@@ -27,24 +27,39 @@ template <class T> struct PackedScene {
     DScene<T> view;  // scalars filled by pack_scene; pointers by whoever owns the memory
 };
 
-inline bool texture_needs_uv(const RtSceneDesc* d, uint32_t tex, int depth) {
-    if (depth > 16) return false;
+// Checker textures nest by index (texture.rs:21-50).  Depth and "needs (u,v)" are computed once per texture index
+// (memoised): a shared sub-texture is not re-expanded once per path leading to it, so a nested chain costs O(n), not 2^n.
+struct TextureInfo {
+    std::vector<int> depth;     // 0 = leaf kinds; 99 = cyclic, out of range or deeper than 16
+    std::vector<char> needs_uv;
+};
+inline void texture_info_visit(const RtSceneDesc* d, uint32_t tex, TextureInfo& ti, std::vector<char>& state) {
+    if (state[tex] == 2) return;
+    if (state[tex] == 1) { ti.depth[tex] = 99; return; }  // on the current descent: a cycle
+    state[tex] = 1;
     const RtTexture& t = d->textures[tex];
-    switch (t.kind) {
-        case RT_TEX_CHECKER_UV: case RT_TEX_IMAGE: return true;
-        case RT_TEX_CHECKER_3D: return texture_needs_uv(d, t.odd, depth + 1) || texture_needs_uv(d, t.even, depth + 1);
-        default: return false;
-    }
-}
-inline int texture_depth(const RtSceneDesc* d, uint32_t tex, int depth) {
-    if (depth > 16) return depth;
-    const RtTexture& t = d->textures[tex];
+    int depth = 0; bool uv = t.kind == RT_TEX_CHECKER_UV || t.kind == RT_TEX_IMAGE;
     if (t.kind == RT_TEX_CHECKER_3D || t.kind == RT_TEX_CHECKER_UV) {
-        if (t.odd >= d->n_textures || t.even >= d->n_textures) return 99;
-        int a = texture_depth(d, t.odd, depth + 1), b = texture_depth(d, t.even, depth + 1);
-        return a > b ? a : b;
+        if (t.odd >= d->n_textures || t.even >= d->n_textures) {
+            depth = 99;
+        } else {
+            texture_info_visit(d, t.odd, ti, state);
+            texture_info_visit(d, t.even, ti, state);
+            const int a = ti.depth[t.odd], b = ti.depth[t.even];
+            depth = (a > b ? a : b) + 1;
+            if (depth > 16) depth = 99;
+            uv = uv || ti.needs_uv[t.odd] || ti.needs_uv[t.even];
+        }
     }
-    return depth;
+    ti.depth[tex] = depth; ti.needs_uv[tex] = uv ? 1 : 0;
+    state[tex] = 2;
+}
+inline TextureInfo texture_info(const RtSceneDesc* d) {
+    TextureInfo ti;
+    ti.depth.assign(d->n_textures, 0); ti.needs_uv.assign(d->n_textures, 0);
+    std::vector<char> state(d->n_textures, 0);
+    for (uint32_t i = 0; i < d->n_textures; i++) texture_info_visit(d, i, ti, state);
+    return ti;
 }
 
 inline int validate_instances(const RtSceneDesc* d, const RtInstance* ins, uint32_t n, const char* what) {
@@ -81,7 +96,11 @@ inline int validate(const RtSceneDesc* d) {
         if (t.kind > RT_TEX_IMAGE) return fail(RT_ERR_INVALID, "texture kind out of range");
         if (t.kind == RT_TEX_NOISE && t.table >= d->n_perlins) return fail(RT_ERR_INVALID, "perlin index out of range");
         if (t.kind == RT_TEX_IMAGE && t.table >= d->n_images) return fail(RT_ERR_INVALID, "image index out of range");
-        if (texture_depth(d, i, 0) > 16) return fail(RT_ERR_UNSUPPORTED, "checker textures nested deeper than 16 (or cyclic / out of range)");
+    }
+    {
+        const TextureInfo ti = texture_info(d);
+        for (uint32_t i = 0; i < d->n_textures; i++)
+            if (ti.depth[i] > 16) return fail(RT_ERR_UNSUPPORTED, "checker textures nested deeper than 16 (or cyclic / out of range)");
     }
     for (uint32_t i = 0; i < d->n_images; i++)
         if (!d->images[i].rgb || d->images[i].width == 0 || d->images[i].height == 0) return fail(RT_ERR_INVALID, "empty image");
@@ -105,16 +124,22 @@ inline int validate(const RtSceneDesc* d) {
     if (b.n_nodes) {
         if (!b.min_x || !b.min_y || !b.min_z || !b.max_x || !b.max_y || !b.max_z || !b.left || !b.right)
             return fail(RT_ERR_INVALID, "NULL BVH array");
+        // a TREE (bvh.rs:79-83: children are owned boxes): every internal node has at most one parent, so threading
+        // the nodes cannot expand one node several times (n nodes with left = right = i+1 would give 2^n entries)
+        std::vector<char> has_parent(b.n_nodes, 0);
         for (uint32_t i = 0; i < b.n_nodes; i++) {
             const int32_t kids[2] = {b.left[i], b.right[i]};
             for (int k = 0; k < 2; k++) {
                 if (kids[k] >= 0) {  // pre-order: a child node always follows its parent -> acyclic
                     if ((uint32_t)kids[k] <= i || (uint32_t)kids[k] >= b.n_nodes) return fail(RT_ERR_INVALID, "BVH child node index not in pre-order range");
+                    if (has_parent[kids[k]]) return fail(RT_ERR_INVALID, "BVH node referenced by more than one parent (the node buffer must hold trees)");
+                    has_parent[kids[k]] = 1;
                 } else if ((uint32_t)(~kids[k]) >= d->n_prims) {
                     return fail(RT_ERR_INVALID, "BVH leaf primitive index out of range");
                 }
             }
         }
+        // an instance root that is also some node's child would be threaded twice (harmless, but bounded: <= n_world + n_lights copies)
     }
     int rc = validate_instances(d, d->world, d->n_world, "world");
     if (rc) return rc;
@@ -210,6 +235,7 @@ inline uint32_t scene_features(const RtSceneDesc* d) {
             default: f |= F_RECT; break;
         }
     }
+    const TextureInfo ti = texture_info(d);
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const RtMaterial& m = d->materials[i];
         if (m.kind == RT_MAT_METAL) f |= F_METAL;
@@ -217,7 +243,7 @@ inline uint32_t scene_features(const RtSceneDesc* d) {
         if (m.kind == RT_MAT_FROSTED_DIELECTRIC) f |= F_DIELECTRIC | F_FROSTED;
         if (m.kind == RT_MAT_ISOTROPIC) f |= F_MEDIUM;
         bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
-        if (textured && texture_needs_uv(d, m.texture, 0)) f |= F_UV;
+        if (textured && ti.needs_uv[m.texture]) f |= F_UV;
     }
     for (uint32_t i = 0; i < d->n_textures; i++) {
         if (d->textures[i].kind != RT_TEX_SOLID) f |= F_TEXTURED;
@@ -235,13 +261,14 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
         p.kind = d->prims[i].kind; p.material = d->prims[i].material;
         h.prims.push_back(p);
     }
+    const TextureInfo ti = texture_info(d);
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const RtMaterial& m = d->materials[i];
         DMaterial<T> o;
         for (int k = 0; k < 3; k++) o.albedo[k] = (T)m.albedo[k];
         o.fuzz = (T)m.fuzz; o.ref_idx = (T)m.ref_idx; o.texture = m.texture;
         bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
-        o.kind = m.kind | ((textured && texture_needs_uv(d, m.texture, 0)) ? 0x100u : 0u);  // bit 8: shading needs (u,v)
+        o.kind = m.kind | ((textured && ti.needs_uv[m.texture]) ? 0x100u : 0u);  // bit 8: shading needs (u,v)
         h.materials.push_back(o);
     }
     for (uint32_t i = 0; i < d->n_textures; i++) {

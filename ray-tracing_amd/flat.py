@@ -249,12 +249,15 @@ def scene_from_json(text, aspect_ratio=None, background=(0.0, 0.0, 0.0)):
     materials Lambertian{albedo: texture} | Metal{albedo,fuzz} | Dielectric{ref_idx} | DiffuseLight{emit: texture};
     textures SolidColor{color} | CheckerTexture{odd,even}; camera{lookfrom,lookat,vup,vfov,aspect_ratio,aperture,focus_dist}.
     As in scenes_file.rs: a BVHNode's box is the surrounding box of its children's boxes over (0,1)
-    (`BvhNodeStatic::new(left, right, 0.0, 1.0)`, :50-56 — the JSON's own bounding_box field is not read),
+    (`BvhNodeStatic::new(left, right, 0.0, 1.0)`, :50-56 — the JSON's own bounding_box field is not used for the scene;
+    it is kept beside it as `fs.json_boxes[node] = [min xyz, max xyz]`: the one place where the reference holds numbers
+    produced by its own Sphere::bounding_box / Aabb::surrounding_box, which tests compare the recomputed boxes with),
     background = Vec3::zero(), lights = None, shutter 0..1 (:161-176).  The proc-macro bakes this into static
     types (and is disabled as shipped, SWITCH = false); here it becomes a flat scene at run time."""
     j = json.loads(text) if isinstance(text, str) else text
     fs = FlatScene()
     fs.background = list(background)
+    fs.json_boxes = {}
 
     def vec(v):
         return [float(v[0]), float(v[1]), float(v[2])] if isinstance(v, (list, tuple)) else [float(v["x"]), float(v["y"]), float(v["z"])]
@@ -284,6 +287,8 @@ def scene_from_json(text, aspect_ratio=None, background=(0.0, 0.0, 0.0)):
             return ("prim", fs.sphere(vec(o["center"]), float(o["radius"]), mat(o["material"])))
         if o["type"] == "BVHNode":
             me = fs.node([0.0] * 6, 0, 0)
+            if "bounding_box" in o:
+                fs.json_boxes[me] = vec(o["bounding_box"]["min"]) + vec(o["bounding_box"]["max"])
             kids, boxes = [], []
             for side in ("left", "right"):
                 k, i = geom(o[side])

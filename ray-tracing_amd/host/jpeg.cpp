@@ -73,13 +73,15 @@ int decode_symbol(Reader& r, const Huff& h, bool& ok) {
 }
 // 8x8 inverse DCT from the definition (T.81 A.3.3), separable, in double
 void idct8x8(const double* in, uint8_t* out, int stride) {
-    static double c[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int x = 0; x < 8; x++)
-            for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
-        init = true;
-    }
+    struct Table {
+        double c[8][8];
+        Table() {
+            for (int x = 0; x < 8; x++)
+                for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        }
+    };
+    static const Table table;  // function-local static: initialised once, thread-safe (two host threads may decode at once)
+    const double (*c)[8] = table.c;
     double tmp[64];
     for (int v = 0; v < 8; v++)          // rows: over u
         for (int x = 0; x < 8; x++) {
@@ -179,6 +181,7 @@ bool decode_jpeg(const uint8_t* data, size_t n, RgbImage& out, std::string& err)
             restart = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {  // SOS: baseline has one interleaved scan (or one per component for non-interleaved files)
             if (!have_sof) return bad("SOS before SOF");
+            if (sl < 1) return bad("truncated SOS segment");
             const int ns = s[0];
             if (ns != (int)comps.size() || sl < 1u + 2u * ns + 3u) return bad("non-interleaved scans are not supported");
             for (int k = 0; k < ns; k++) {

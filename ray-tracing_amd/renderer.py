@@ -131,6 +131,20 @@ class DeviceScene:
         with torch.cuda.device(self.device):
             check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), sp, self._stream()))
 
+    def render_rgb8(self, width, height, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
+                    max_nan_retries=64, no_sort=False, out=None):
+        """ray_tracing.rs:95-118 in one call -> uint8 CUDA tensor [H, W, 3], top row first (rt_render_rgb8;
+        `out` = a preallocated result tensor)."""
+        p = RtRenderParams(int(width), int(height), int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
+                           _PRECISION[precision], 1 if no_sort else 0)
+        sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
+        with torch.cuda.device(self.device):
+            rgb = out if out is not None else torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
+            assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.numel() == width * height * 3
+            fn = _ffi.hip().rt_render_rgb8
+            check(fn(self._h, C.byref(p), C.c_void_p(rgb.data_ptr()), sp, self._stream()))
+        return rgb
+
     def sample_pixel(self, width, height, x, y, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f64"):
         p = RtRenderParams(width, height, int(spp_begin), int(spp_count), int(max_depth), 64, int(seed), _PRECISION[precision], 0)
         with torch.cuda.device(self.device):
@@ -158,6 +172,58 @@ def resolve(accum, spp):
     with torch.cuda.device(accum.device):
         check(_ffi.hip().rt_resolve(C.c_void_p(accum.data_ptr()), w, h, int(spp), C.c_void_p(rgb.data_ptr()), stream))
     return rgb
+
+
+class Comm:
+    """The exchange step through the C-ABI (rt_comm_* / rt_allreduce_*: one RCCL all-reduce of the accumulation
+    buffers).  `broadcast_bytes(b: bytes or None) -> bytes` ships rank 0's 128-byte id to every rank (any
+    transport: torch.distributed, a file, MPI); it is not needed for a single rank."""
+
+    def __init__(self, rank=0, world_size=1, broadcast_bytes=None, device=None):
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        if self.device not in _inited:
+            init(self.device)
+        self.rank, self.world_size = int(rank), int(world_size)
+        buf = (C.c_uint8 * _ffi.RT_COMM_ID_BYTES)()
+        if self.rank == 0:
+            check(_ffi.hip().rt_comm_unique_id(buf))
+        if self.world_size > 1:
+            if broadcast_bytes is None:
+                raise ValueError("world_size > 1 needs broadcast_bytes to ship the communicator id")
+            raw = broadcast_bytes(bytes(buf) if self.rank == 0 else None)
+            buf = (C.c_uint8 * _ffi.RT_COMM_ID_BYTES).from_buffer_copy(raw)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_ffi.hip().rt_comm_create(buf, self.world_size, self.rank, C.byref(h)))
+        self._h = h
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def all_reduce(self, accum):
+        """In-place sum over ranks of a float32 CUDA tensor (the accumulation buffer), on the current stream."""
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous()
+        with torch.cuda.device(self.device):
+            check(_ffi.hip().rt_allreduce_accum(self._h, C.c_void_p(accum.data_ptr()), accum.numel(), self._stream()))
+        return accum
+
+    def all_reduce_stats(self, stats):
+        assert stats.is_cuda and stats.dtype == torch.int64 and stats.numel() == _ffi.RT_STATS_WORDS
+        with torch.cuda.device(self.device):
+            check(_ffi.hip().rt_allreduce_stats(self._h, C.c_void_p(stats.data_ptr()), self._stream()))
+        return stats
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            _ffi.hip().rt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def spp_shard(spp, rank, world_size):
@@ -234,9 +300,20 @@ def render_progressive(scene, width, height, spp, pass_spp, seed=DEFAULT_SEED, m
         for k, v in ident.items():
             if meta.get(k) != v:
                 raise ValueError(f"checkpoint {checkpoint} is of another render: {k} = {meta.get(k)!r}, wanted {v!r}")
+        if meta.get("precision", precision) != precision:  # f32 and f64 samples are different estimates: do not mix them silently
+            raise ValueError(f"checkpoint {checkpoint} was rendered in {meta.get('precision')}, this run asks for {precision}")
         done = int(meta["spp_done"])
+        if done < 0 or done > spp:
+            raise ValueError(f"checkpoint {checkpoint} holds {done} samples per pixel, more than the {spp} asked for")
         if rank == 0:  # the sums so far enter the all-reduce once
             accum += torch.from_numpy(arr).to(accum.device)
+    if all_reduce is not None and world_size > 1:
+        # every rank must start from the same sample count (a checkpoint file that only some ranks can see would make
+        # the passes, and with them the all-reduce calls, differ): sum d and d^2 over the ranks; all equal <=> N*sum(d^2) == sum(d)^2
+        chk = torch.tensor([float(done), float(done) * float(done)], dtype=torch.float64, device=accum.device)
+        all_reduce(chk)
+        if abs(world_size * chk[1].item() - chk[0].item() ** 2) > 0.5:
+            raise ValueError(f"ranks disagree on the checkpoint's spp_done (this rank: {done}): put {checkpoint} where every rank reads the same file")
     while done < spp:
         n = min(int(pass_spp), spp - done)
         begin, count = spp_shard(n, rank, world_size)

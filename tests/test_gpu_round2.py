@@ -1,0 +1,238 @@
+"""GPU tests added in round 2 (all through the C-ABI): the exchange step, the one-call rgb8 entry point, progressive
+rendering with checkpoint/resume on the device, an ImageTexture fed through the in-repo JPEG decoder, the job-counter
+ring under more launches in flight than it has slots, and property runs at BASELINE's full frame sizes."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ray_tracing_amd as rt
+from oracle_lib import OracleScene, resolve as oracle_resolve
+from ray_tracing_amd import _ffi, flat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scenes(gpu):
+    cache = {}
+
+    def get(name, aspect=1.0):
+        key = (name, aspect)
+        if key not in cache:
+            hs = rt.HostScene(name, aspect)
+            cache[key] = (hs, rt.DeviceScene(hs, 0))
+        return cache[key][1]
+
+    yield get
+    for hs, ds in cache.values():
+        ds.close()
+        hs.close()
+
+
+# ---- exchange step (SURVEY §8 b-4 / e): rt_comm_* + rt_allreduce_* ------------------------------------------
+def test_exchange_single_rank_is_identity_and_errors_are_codes(scenes):
+    lib = _ffi.hip()
+    comm = rt.Comm(0, 1)  # rt_comm_unique_id + rt_comm_create on device 0: a 1-rank RCCL communicator
+    ds = scenes("cornell_box")
+    acc = torch.zeros((64, 64, 3), dtype=torch.float32, device="cuda:0")
+    st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    ds.render_into(acc, 0, 4, precision="f64", stats=st)
+    before, st_before = acc.clone(), st.clone()
+    comm.all_reduce(acc)           # sum over one rank: unchanged, bit for bit
+    comm.all_reduce_stats(st)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, before) and torch.equal(st, st_before)
+    # a full-size buffer (the 12.6 MB of BASELINE's frame)
+    big = torch.rand((1024, 1024, 3), dtype=torch.float32, device="cuda:0")
+    ref = big.clone()
+    comm.all_reduce(big)
+    torch.cuda.synchronize()
+    assert torch.equal(big, ref)
+    # errors come back as codes
+    assert lib.rt_allreduce_accum(None, C.c_void_p(acc.data_ptr()), 12, None) == 1
+    assert lib.rt_allreduce_accum(comm._h, None, 12, None) == 1
+    assert lib.rt_allreduce_accum(comm._h, None, 0, None) == 0
+    assert lib.rt_allreduce_stats(comm._h, None, None) == 1
+    h = C.c_void_p()
+    buf = (C.c_uint8 * 128)()
+    assert lib.rt_comm_create(buf, 2, 2, C.byref(h)) == 1 and b"rank" in lib.rt_last_error()
+    assert lib.rt_comm_create(None, 1, 0, C.byref(h)) == 1
+    assert lib.rt_comm_adopt(None, C.byref(h)) == 1
+    assert lib.rt_comm_destroy(None) == 0
+    comm.close()
+
+
+def test_render_shards_plus_exchange_equal_one_render(scenes):
+    # what N GPUs do, on one: N disjoint sample shards rendered into separate buffers, summed, == one render of all samples.
+    # (the sum over buffers is what the all-reduce computes; the communicator here has one rank)
+    ds = scenes("cornell_box")
+    W = H = 96
+    whole = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    ds.render_into(whole, 0, 64, precision="f64")
+    parts = []
+    for r in range(8):
+        b, c = rt.spp_shard(64, r, 8)
+        p = torch.zeros_like(whole)
+        ds.render_into(p, b, c, precision="f64")
+        parts.append(p)
+    total = torch.stack(parts).sum(0)
+    assert torch.allclose(total, whole, rtol=2e-6, atol=1e-6)
+
+
+# ---- rt_render_rgb8: ray_tracing.rs:95-118 in one call -------------------------------------------------------
+@pytest.mark.parametrize("name,W,H,spp", (("cornell_box", 64, 48, 32), ("random_scene", 72, 40, 4), ("earth", 33, 21, 3)))
+def test_render_rgb8_equals_render_then_resolve(name, W, H, spp, scenes):
+    ds = scenes(name, W / H)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    st_a = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    st_b = torch.zeros_like(st_a)
+    ds.render_into(acc, 5, spp, precision="f64", stats=st_a)
+    want = rt.resolve(acc, spp)
+    got = ds.render_rgb8(W, H, 5, spp, precision="f64", stats=st_b)
+    # sample chunks added by float atomics can differ in the last bit of a sum: allow one grey level on a few pixels
+    d = (got.int() - want.int()).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3
+    assert st_a.tolist() == st_b.tolist()
+    # and against the oracle's image of the same samples
+    ref, _ = OracleScene(name, W / H).render(W, H, 5, spp, threads=8)
+    d = np.abs(got.cpu().numpy().astype(int) - oracle_resolve(ref, spp).astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 2e-3
+    # a second, larger frame regrows the work buffer; then the small one again
+    got2 = ds.render_rgb8(2 * W, 2 * H, 0, 2, precision="f64")
+    assert got2.shape == (2 * H, 2 * W, 3)
+    again = ds.render_rgb8(W, H, 5, spp, precision="f64")
+    assert (again.int() - got.int()).abs().max().item() <= 1
+    with pytest.raises(rt.RtError):
+        ds.render_rgb8(W, H, 0, 0)
+
+
+# ---- f4 on the device: progressive passes, checkpoint, resume ------------------------------------------------
+def test_progressive_checkpoint_resume_on_device(scenes, tmp_path):
+    ds = scenes("cornell_smoke")
+    W, H, SPP = 56, 40, 24
+    whole = rt.render(ds, W, H, SPP, precision="f64")
+    seen = []
+    acc, done = rt.render_progressive(ds, W, H, SPP, 8, precision="f64", spp_per_launch=5, on_pass=lambda d, t: seen.append(d))
+    assert done == SPP and seen == [8, 16, 24]
+    assert torch.allclose(acc, whole, rtol=2e-6, atol=1e-6)
+    # stop after 16 samples (2 passes), continue from the file in 3 passes of other sizes
+    path = str(tmp_path / "smoke.rtck")
+    part, d16 = rt.render_progressive(ds, W, H, 16, 8, precision="f64", checkpoint=path, scene_name="cornell_smoke")
+    arr, meta = rt.load_checkpoint(path)
+    assert d16 == 16 and meta["spp_done"] == 16 and meta["precision"] == "f64" and np.array_equal(arr, part.cpu().numpy())
+    full, d24 = rt.render_progressive(ds, W, H, SPP, 3, precision="f64", checkpoint=path, resume=True, scene_name="cornell_smoke")
+    assert d24 == SPP and rt.load_checkpoint(path)[1]["spp_done"] == SPP
+    assert torch.allclose(full, whole, rtol=2e-6, atol=1e-6)
+    # the resumed render's 8-bit image is the one-go render's
+    assert (rt.resolve(full, SPP).int() - rt.resolve(whole, SPP).int()).abs().max().item() <= 1
+    # a checkpoint of another precision / with more samples than asked for is refused
+    with pytest.raises(ValueError):
+        rt.render_progressive(ds, W, H, SPP, 3, precision="f32", checkpoint=path, resume=True, scene_name="cornell_smoke")
+    with pytest.raises(ValueError):
+        rt.render_progressive(ds, W, H, 8, 3, precision="f64", checkpoint=path, resume=True, scene_name="cornell_smoke")
+
+
+# ---- ImageTexture through the in-repo JPEG decoder (src/texture.rs:68-74) ------------------------------------
+def test_earth_frame_from_jpeg_equals_frame_from_its_raster(gpu, golden_dir, tmp_path):
+    jpg = os.path.join(golden_dir, "earth_256x128.jpg")  # committed baseline JPEG (tools/make_small_jpeg.py)
+    lib = C.CDLL(_ffi.LIB_HOST)
+    lib.rth_image_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.rth_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    p, w, h = C.POINTER(C.c_uint8)(), C.c_uint32(), C.c_uint32()
+    assert lib.rth_image_load(jpg.encode(), C.byref(p), C.byref(w), C.byref(h)) == 0
+    raster = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    lib.rth_image_free(p)
+    assert raster.shape == (128, 256, 3) and raster.std() > 10
+    ppm = str(tmp_path / "earth_small.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n256 128\n255\n" + raster.tobytes())
+    W, H, spp = 96, 64, 8
+    frames = []
+    for path in (jpg, ppm):
+        hs = rt.HostScene("earth", W / H, image_path=path)
+        assert hs.desc.n_images == 1 and (hs.desc.images[0].width, hs.desc.images[0].height) == (256, 128)
+        ds = rt.DeviceScene(hs, 0)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64")
+        frames.append(acc.cpu().numpy())
+        ds.close(); hs.close()
+    assert np.array_equal(frames[0], frames[1])  # same texels -> same frame, bit for bit
+    # and it is the oracle's frame for that raster (the texture is really sampled: the frame differs from the default asset's)
+    ref, _ = OracleScene("earth", W / H, image_path=ppm).render(W, H, 0, spp, threads=8)
+    assert (np.abs(frames[0] - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2).mean() >= 0.998
+    ref_default, _ = OracleScene("earth", W / H).render(W, H, 0, spp, threads=8)
+    assert np.abs(ref - ref_default).max() > 0.05
+
+
+# ---- job-counter ring: more launches in flight than slots, on two streams ------------------------------------
+def test_more_launches_in_flight_than_ring_slots(scenes):
+    ds = scenes("random_scene", 1.5)  # persistent kernel: draws jobs from the ring's counters
+    W, H, spp = 48, 32, 2
+    n = 150  # > 2 x 64 slots
+    want = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    ds.render_into(want, 0, spp, precision="f32")
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros((n // 2 + 1, H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        k = i & 1
+        with torch.cuda.stream(streams[k]):
+            ds.render_into(bufs[k][i // 2], 0, spp, precision="f32")
+    torch.cuda.synchronize()
+    for k in range(2):
+        for j in range(n // 2):
+            assert torch.allclose(bufs[k][j], want, rtol=2e-6, atol=1e-6), (k, j)
+
+
+# ---- BASELINE frame sizes: properties that need no oracle frame ----------------------------------------------
+@pytest.mark.parametrize("name,W,H,spp", (("random_scene", 800, 450, 6), ("cornell_smoke", 1024, 1024, 6), ("final_scene", 2048, 2048, 2)))
+def test_full_size_frames_properties(name, W, H, spp, scenes):
+    # C1 800x450, C4 1024^2, C5 2048^2: job/grid arithmetic at the real sizes.  (1) the probe equals the oracle's on a strided
+    # subset of rows (the whole grid for C1); (2) sample ranges are additive; (3) every sample counted once; (4) finite sums.
+    aspect = W / H
+    ds = scenes(name, aspect)
+    oc = OracleScene(name, aspect)
+    ids, ts = ds.trace_primary(W, H, 0.5, 0.4, "f64")
+    if W * H <= 800 * 450:
+        oi, ot = oc.trace_primary(W, H, 0.5, 0.4)
+        assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot)
+    else:
+        # the oracle's probe is a full-grid call: compare on the sub-grid of every s-th pixel, s a common divisor of W-1
+        # and H-1.  u = (s k)/(W-1) and k/((W-1)/s) are the same rational from exactly representable operands, and IEEE
+        # division rounds correctly: the two grids' rays are bit-identical, so ids and t must be too.
+        s_ = next(k for k in (3, 23, 5, 7, 11, 31) if (W - 1) % k == 0 and (H - 1) % k == 0)
+        w3, h3 = (W - 1) // s_ + 1, (H - 1) // s_ + 1
+        oi, ot = oc.trace_primary(w3, h3, 0.5, 0.4)
+        gi, gt = ids.cpu().numpy()[::s_, ::s_], ts.cpu().numpy()[::s_, ::s_]
+        assert gi.shape == oi.shape and np.array_equal(gi, oi) and np.array_equal(gt, ot)
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    b = torch.zeros_like(a)
+    sa = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    sb = torch.zeros_like(sa)
+    ds.render_into(a, 0, spp, precision="f64", stats=sa)
+    ds.render_into(b, 0, spp // 2, precision="f64", stats=sb)
+    ds.render_into(b, spp // 2, spp - spp // 2, precision="f64", stats=sb)
+    assert torch.allclose(a, b, rtol=2e-6, atol=2e-6)
+    assert sa.tolist() == sb.tolist() and sa[0].item() + sa[3].item() == W * H * spp
+    assert torch.isfinite(a).all()
+
+
+def test_json_scene_boxes_on_the_device_path(gpu, golden_dir):
+    # the SoA node boxes handed to rt_scene_create for the reference's JSON scenes equal the boxes stored in those files
+    # (tests/test_json_boxes.py has the CPU side), and the device probe over exactly those arrays equals the fixture
+    for fixture in ("json_scene10", "json_scene_500"):
+        fx = np.load(os.path.join(golden_dir, fixture + ".npz"))
+        host = rt.FlatHostScene(flat.FlatScene.from_dict(json.loads(str(fx["flat_scene"]))))
+        d = host.desc
+        n = d.bvh.n_nodes
+        soa = np.stack([np.ctypeslib.as_array(getattr(d.bvh, k), shape=(n,)) for k in ("min_x", "min_y", "min_z", "max_x", "max_y", "max_z")], axis=1)
+        assert np.abs(soa - fx["json_boxes"]).max() <= 1e-6
+        ds = rt.DeviceScene(host, 0)
+        ids, ts = ds.trace_primary(64, 64, 0.0, 0.5, "f64")
+        assert np.array_equal(ids.cpu().numpy(), fx["ids"]) and np.array_equal(ts.cpu().numpy(), fx["t"])
+        ds.close()
