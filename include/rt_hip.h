@@ -231,8 +231,17 @@ int rt_resolve(const float* d_accum, uint32_t width, uint32_t height, uint32_t s
 /* The whole per-pixel block src/ray_tracing.rs:95-118 in one call (sample loop AND tonemap: the reference's jobs
  * return `Vec<[u8;3]>`): d_rgb = 8-bit image (top row first) of the mean of samples [spp_begin, spp_begin+spp_count).
  * The float sums between the two kernels live in a work buffer owned by the scene handle; this call hipMallocs it
- * when the frame outgrows it (so it must not be used under stream capture). */
+ * when the frame outgrows it (so it must not be used under stream capture: see rt_render_rgb8_noalloc). */
 int rt_render_rgb8(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb, uint64_t* d_stats, void* stream);
+
+/* No counterpart in the reference.  rt_render_rgb8 for callers that CANNOT ALLOCATE (HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): same kernels, same output, but the float sums and the job
+ * counter live in a static device array of the library (RT_NOALLOC_MAX_PIXELS x 12 bytes + 256, held on every GPU
+ * the library runs on until the process ends).  Calls no hipMalloc / hipFree / event creation.  Frames of more than
+ * RT_NOALLOC_MAX_PIXELS pixels are rejected with RT_ERR_INVALID.  rt_init(device) must have run on the device.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two scenes) race. */
+#define RT_NOALLOC_MAX_PIXELS (1024u * 1024u)
+int rt_render_rgb8_noalloc(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb, uint64_t* d_stats, void* stream);
 
 /* ---- multi-GPU exchange step -----------------------------------------------------------------------------
  * Replaces the one gather the reference has: worker jobs -> mpsc channel -> the single image

@@ -10,6 +10,7 @@ LIB_HOST = os.path.join(PKG, "librt_host.so")
 RT_F32, RT_F64 = 0, 1
 RT_STATS_WORDS = 4
 RT_COMM_ID_BYTES = 128
+RT_NOALLOC_MAX_PIXELS = 1024 * 1024
 
 
 class RtRenderParams(C.Structure):
@@ -56,6 +57,7 @@ def hip():
             "rt_debug_sample_pixel": ([vp, C.POINTER(RtRenderParams), u32, u32, vp, vp], C.c_int),
             "rt_resolve": ([vp, u32, u32, u32, vp, vp], C.c_int),
             "rt_render_rgb8": ([vp, C.POINTER(RtRenderParams), vp, vp, vp], C.c_int),
+            "rt_render_rgb8_noalloc": ([vp, C.POINTER(RtRenderParams), vp, vp, vp], C.c_int),
             "rt_comm_unique_id": ([vp], C.c_int),
             "rt_comm_create": ([vp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
             "rt_comm_adopt": ([vp, C.POINTER(vp)], C.c_int),

@@ -23,7 +23,16 @@ using rt::fail;
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Static device scratch of rt_render_rgb8_noalloc: [0,256) job counter, then RT_NOALLOC_MAX_PIXELS x 3 float sums.
+// In host code the array's NAME is only a stand-in: rt_init() resolves its device address once per device with
+// hipGetSymbolAddress and everything below uses that pointer.
+constexpr int kMaxDevices = 64;
+constexpr size_t kScratchHeader = 256;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
 }  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kScratchHeader + (size_t)RT_NOALLOC_MAX_PIXELS * 3u * sizeof(float)];
 
 struct RtScene {
     int device = 0;
@@ -105,6 +114,11 @@ int rt_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RT_ERR_NO_DEVICE, std::string("this library contains gfx950 code only; device is ") + prop.gcnArchName);
+    if (device < kMaxDevices && !g_scratch_ptr[device]) {  // once per device, with that device current
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
     g_desc = "rt_hip abi=" + std::to_string(RT_ABI_VERSION) + " " + prop.gcnArchName + " cu=" + std::to_string(prop.multiProcessorCount) +
              " clock_mhz=" + std::to_string(prop.clockRate / 1000);
     return RT_OK;
@@ -199,7 +213,7 @@ static int make_args(const RtRenderParams* p, rt::RenderArgs& a) {
     return RT_OK;
 }
 
-// One render launch with the job-counter word the caller chose (a slot of the scene's ring).
+// One render launch with the job-counter word the caller chose (ring slot of the scene, or static scratch).
 static int render_launch(RtScene* scene, const RtRenderParams* params, const rt::RenderArgs& a, uint32_t* d_counter, float* d_accum,
                          uint64_t* d_stats, hipStream_t stream) {
     const rt::LaunchCtx ctx{d_counter, scene->cu_count};
@@ -268,6 +282,30 @@ int rt_render_rgb8(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb,
     if ((rc = render_launch(scene, params, a, scene->d_counters + slot, scene->d_work, d_stats, (hipStream_t)stream))) return rc;
     if ((rc = ring_release(scene, (hipStream_t)stream, slot, capturing))) return rc;
     HIP_TRY(rt::launch_resolve(scene->d_work, a.width, a.height, a.spp_count, d_rgb, (hipStream_t)stream));
+    return RT_OK;
+}
+
+// rt_render_rgb8 for callers that cannot allocate (HIP graph capture, serving loops): the same two kernels, with the
+// float sums and the job counter in the library's static device array `scratch`.  Calls no hipMalloc / hipFree /
+// event creation.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
+int rt_render_rgb8_noalloc(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb, uint64_t* d_stats, void* stream) {
+    int rc = check_scene(scene);
+    if (rc) return rc;
+    rt::RenderArgs a;
+    if ((rc = make_args(params, a))) return rc;
+    if (!d_rgb) return fail(RT_ERR_INVALID, "d_rgb is NULL");
+    if (a.spp_count == 0) return fail(RT_ERR_INVALID, "spp_count must be > 0 (the image is the mean of the samples)");
+    if ((uint64_t)a.width * a.height > RT_NOALLOC_MAX_PIXELS)
+        return fail(RT_ERR_INVALID, "rt_render_rgb8_noalloc: frame of " + std::to_string((uint64_t)a.width * a.height) + " pixels exceeds the static scratch (RT_NOALLOC_MAX_PIXELS = " +
+                                        std::to_string((uint64_t)RT_NOALLOC_MAX_PIXELS) + "); use rt_render_rgb8 or rt_render");
+    unsigned char* base = scene->device >= 0 && scene->device < kMaxDevices ? g_scratch_ptr[scene->device] : nullptr;
+    if (!base) return fail(RT_ERR_INVALID, "rt_render_rgb8_noalloc: call rt_init(device) on this device first (it resolves the scratch array's address)");
+    uint32_t* d_counter = (uint32_t*)base;                  // first 256 bytes: job counter of the persistent kernel
+    float* d_sums = (float*)(base + kScratchHeader);        // then W*H*3 float sums
+    const uint64_t floats = (uint64_t)a.width * a.height * 3u;
+    HIP_TRY(hipMemsetAsync(d_sums, 0, floats * sizeof(float), (hipStream_t)stream));  // the array keeps the last call's contents
+    if ((rc = render_launch(scene, params, a, d_counter, d_sums, d_stats, (hipStream_t)stream))) return rc;  // (the launcher zeroes the counter)
+    HIP_TRY(rt::launch_resolve(d_sums, a.width, a.height, a.spp_count, d_rgb, (hipStream_t)stream));
     return RT_OK;
 }
 

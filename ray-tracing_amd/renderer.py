@@ -132,16 +132,16 @@ class DeviceScene:
             check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), sp, self._stream()))
 
     def render_rgb8(self, width, height, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
-                    max_nan_retries=64, no_sort=False, out=None):
-        """ray_tracing.rs:95-118 in one call -> uint8 CUDA tensor [H, W, 3], top row first (rt_render_rgb8;
-        `out` = a preallocated result tensor)."""
+                    max_nan_retries=64, no_sort=False, noalloc=False, out=None):
+        """ray_tracing.rs:95-118 in one call -> uint8 CUDA tensor [H, W, 3], top row first (rt_render_rgb8, or the
+        allocation-free rt_render_rgb8_noalloc with noalloc=True; `out` = a preallocated result tensor)."""
         p = RtRenderParams(int(width), int(height), int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
                            _PRECISION[precision], 1 if no_sort else 0)
         sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
         with torch.cuda.device(self.device):
             rgb = out if out is not None else torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
             assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.numel() == width * height * 3
-            fn = _ffi.hip().rt_render_rgb8
+            fn = _ffi.hip().rt_render_rgb8_noalloc if noalloc else _ffi.hip().rt_render_rgb8
             check(fn(self._h, C.byref(p), C.c_void_p(rgb.data_ptr()), sp, self._stream()))
         return rgb
 

@@ -22,7 +22,7 @@ PYT="python -u -m pytest -x -v --timeout 240 --timeout-method thread"
 for w in $WHAT; do
 case $w in
 new) step pytest_new 600 $PYT tests/test_gpu_round2.py > "$OUT/pytest_new.log" 2>&1 || { tail -40 "$OUT/pytest_new.log"; exit 1; }; tail -3 "$OUT/pytest_new.log";;
-wip) step pytest_wip 300 $PYT tests/wip_no_alloc.py > "$OUT/pytest_wip.log" 2>&1 || { tail -40 "$OUT/pytest_wip.log"; exit 1; }; tail -3 "$OUT/pytest_wip.log";;
+wip) step pytest_wip 300 $PYT tests/test_zz_no_alloc.py > "$OUT/pytest_wip.log" 2>&1 || { tail -40 "$OUT/pytest_wip.log"; exit 1; }; tail -3 "$OUT/pytest_wip.log";;
 all) step pytest_gpu 1000 $PYT tests -m gpu > "$OUT/pytest_gpu.log" 2>&1 || { tail -40 "$OUT/pytest_gpu.log"; exit 1; }; tail -3 "$OUT/pytest_gpu.log";;
 bench) step bench 600 python -u bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }; cat "$OUT/bench.json";;
 torchrun) step torchrun1 600 python -u -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-f32 > "$OUT/torchrun1.json" 2> "$OUT/torchrun1.err" || { tail -20 "$OUT/torchrun1.err"; exit 1; }; cat "$OUT/torchrun1.json";;
