@@ -269,6 +269,11 @@ int rt_allreduce_stats(RtComm* comm, uint64_t* d_stats, void* stream);
  * comparison of the RT_F64 path with the CPU oracle (same keyed RNG stream). */
 int rt_debug_sample_pixel(RtScene* scene, const RtRenderParams* params, uint32_t x, uint32_t y, double* d_out, void* stream);
 
+/* Test hook, no counterpart in the reference: the device path divides through a shared-denominator routine
+ * (rt_device.hpp: Recip) that must equal IEEE division bit for bit; d_shared[i] = n[i]/d[i] by that routine,
+ * d_plain[i] by the compiler's `/`. */
+int rt_debug_divide(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, void* stream);
+
 /* Small helpers so a host without another HIP binding can drive the library. */
 int rt_device_alloc(void** d_ptr, uint64_t bytes);
 int rt_device_free(void* d_ptr);

@@ -109,11 +109,13 @@ template <class T> struct DScene {
     const DXform<T>* xforms;
     const DInstance<T>* world;
     const DInstance<T>* lights;
-    const DBvhEntry<T>* bvh;
+    const DBvhEntry<T>* bvh;        // the REFERENCE's trees, threaded, exact boxes (walk_run: exact emulation of bvh.rs:114-129)
     const int32_t* bvh_root_entry;  // node index (RtBvh numbering) -> entry index, for instance roots
     const DBvhLite* bvh_lite;       // same indexing as bvh
-    const DBvhLite* bvh_lds;        // entries [0, n_bvh_lds) of bvh_lite staged in LDS by the render kernel (else n_bvh_lds = 0)
-    uint32_t n_bvh, n_bvh_lds;
+    const DBvhLite* fast_lite;      // the device's OWN trees over the same leaves (SAH, rt_pack.hpp), threaded (walk_fast)
+    const int32_t* fast_root_entry; // node index (RtBvh numbering) -> entry index in fast_lite
+    const DBvhLite* bvh_lds;        // entries [0, n_bvh_lds) of fast_lite staged in LDS by the render kernel (else n_bvh_lds = 0)
+    uint32_t n_bvh, n_bvh_lds;      // n_bvh: entries of fast_lite (= of bvh: same leaves, same number of internal nodes)
     const DPerlin<T>* perlin_lds;     // perlins [0, n_perlin_lds) staged in LDS by the render kernel (else n_perlin_lds = 0)
     uint32_t n_perlins, n_perlin_lds;
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
@@ -163,6 +165,70 @@ __device__ inline float rmin(float a, float b) { return ::fminf(a, b); }
 __device__ inline double rmax(double a, double b) { return ::fmax(a, b); }
 __device__ inline float rmax(float a, float b) { return ::fmaxf(a, b); }
 
+// ------------------------------------------------------------------------------------------
+// Exact IEEE-754 division with a SHARED denominator.
+// The reference divides (true f64 `/`): every quotient here must be the correctly rounded one.  hipcc expands an f64
+// division into  div_scale x2, rcp, 4 fma (Newton on the reciprocal), mul, fma (residual), div_fmas, div_fixup  —
+// 11 instructions, one of them quarter-rate — and nothing of that is shared between divisions by the same value
+// (div_scale ties the scaled denominator to each numerator).  Most divisions on this path do share their denominator:
+// the three components of unit(v) / of `v / s`, the two roots of a sphere, and the plane distances (k - o)/d of all
+// rectangles on one axis of one ray (13 rectangle tests per Cornell cast divide by 5 distinct values).
+// Recip<double>(d) runs the reciprocal part once; div(n) is then mul + fma + fma + div_fixup: the same operations, in
+// the same order, as the compiler's expansion with its scaling switched off, so the result is bit-identical whenever
+// div_scale would not have scaled.  That is guaranteed by exponent guards (|d| and |n| in [2^-400, 2^400]: no
+// intermediate can overflow or go subnormal); outside them — zero, subnormal, huge, inf, NaN — div() is the plain `/`.
+// tests/test_gpu_divide.py checks div() against `/` bit for bit on the GPU, edge cases included.
+// MEASURED (profiles/r02_shared_recip.md): with the guards the render kernels LOSE (cornell_box 3126 -> 2786 Msamples/s:
+// a VALU compare -> SALU -> branch dependency per division); without them cornell_box gains 7 % and cornell_smoke loses
+// 7 % (the reciprocals stay live across the instance loop: spills).  So the render kernels divide plainly (Recip<T> below
+// is the plain form) unless built with -DRT_SHARED_RECIP; the routine and its test are kept for a sticky-taint scheme
+// (guards accumulated without branches, tainted samples replayed with plain division).
+// ------------------------------------------------------------------------------------------
+template <class T> struct Recip {
+    T d;
+    __device__ explicit Recip(T d_) : d(d_) {}
+    __device__ T div(T n) const { return n / d; }
+};
+template <class T> struct SharedRecip : Recip<T> { __device__ explicit SharedRecip(T d_) : Recip<T>(d_) {} };
+#if !defined(RT_HOST_SIM) && defined(__HIP_DEVICE_COMPILE__)
+template <> struct SharedRecip<double> {
+    double d, r;
+    bool ok;
+    static __device__ inline bool moderate(double x) {  // biased exponent in [1023-400, 1023+400)
+        const uint32_t e = ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu;
+        return e - 623u < 800u;
+    }
+    __device__ explicit SharedRecip(double d_) : d(d_) {
+        double r0 = __builtin_amdgcn_rcp(d_);
+        double e = __builtin_fma(-d_, r0, 1.0);
+        r0 = __builtin_fma(e, r0, r0);
+        e = __builtin_fma(-d_, r0, 1.0);
+        r = __builtin_fma(e, r0, r0);
+        ok = moderate(d_);
+    }
+    __device__ double div(double n) const {
+        // wave-uniform choice (both routes give the same bits inside the guards, so a whole wave may take either):
+        // one scalar branch instead of an exec-masked region per division
+        // (the plain route is marked unlikely so that it is laid out of line: the common route then has no taken branch)
+#ifndef RT_RECIP_NOGUARD  // (A/B measurement only: what the guards cost)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ok && moderate(n))) != 0, 0)) return n / d;
+#endif
+        const double q = n * r;
+        const double e = __builtin_fma(-d, q, n);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+    }
+};
+#if defined(RT_SHARED_RECIP)
+template <> struct Recip<double> : SharedRecip<double> { __device__ explicit Recip(double d_) : SharedRecip<double>(d_) {} };
+#endif
+#endif
+// A division whose denominator nothing else shares (same interface, plain `/`)
+template <class T> struct PlainDiv {
+    T d;
+    __device__ explicit PlainDiv(T d_) : d(d_) {}
+    __device__ T div(T n) const { return n / d; }
+};
+
 template <class T> struct V3 {
     T x, y, z;
     __device__ V3() {}
@@ -174,7 +240,7 @@ template <class T> __device__ inline V3<T> operator+(V3<T> a, V3<T> b) { return 
 template <class T> __device__ inline V3<T> operator-(V3<T> a, V3<T> b) { return V3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
 template <class T> __device__ inline V3<T> operator-(V3<T> a) { return V3<T>(-a.x, -a.y, -a.z); }
 template <class T> __device__ inline V3<T> operator*(V3<T> a, T b) { return V3<T>(a.x * b, a.y * b, a.z * b); }
-template <class T> __device__ inline V3<T> operator/(V3<T> a, T b) { return V3<T>(a.x / b, a.y / b, a.z / b); }
+template <class T> __device__ inline V3<T> operator/(V3<T> a, T b) { const Recip<T> r(b); return V3<T>(r.div(a.x), r.div(a.y), r.div(a.z)); }
 template <class T> __device__ inline T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 template <class T> __device__ inline T sqlen(V3<T> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 template <class T> __device__ inline T length(V3<T> a) { return sqrt_r(a.x * a.x + a.y * a.y + a.z * a.z); }
@@ -183,7 +249,7 @@ template <class T> __device__ inline V3<T> cross(V3<T> a, V3<T> b) {
     return V3<T>(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
 // src/vec3.rs:30-36; a zero vector yields NaN (the reference panics) -> the sample is retried
-template <class T> __device__ inline V3<T> unit(V3<T> a) { T len = length(a); return V3<T>(a.x / len, a.y / len, a.z / len); }
+template <class T> __device__ inline V3<T> unit(V3<T> a) { const Recip<T> r(length(a)); return V3<T>(r.div(a.x), r.div(a.y), r.div(a.z)); }
 template <class T> __device__ inline V3<T> sel(bool c, V3<T> a, V3<T> b) { return V3<T>(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 template <class T> struct Ray { V3<T> ori, dir; T time; };
@@ -315,22 +381,33 @@ template <class T> __device__ inline Ray<T> get_ray(const DCamera<T>& c, T s, T 
 // ------------------------------------------------------------------------------------------
 // src/objects.rs:227-244, 281-298, 335-352.  axis 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x).
 // Select form: the in-plane point is computed for every lane; the comparisons are the reference's.
-template <class T>
-__device__ inline bool rect_hit(int axis, T a1, T a2, T b1, T b2, T k, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
-    const T ok = axis == 0 ? o.z : (axis == 1 ? o.y : o.x), dk = axis == 0 ? d.z : (axis == 1 ? d.y : d.x);
+// The reciprocals of a ray's direction components, shared by every rectangle test of that ray in one space
+// (world, or an instance's object space): see Recip.
+template <class T> struct RayInv {
+    Recip<T> x, y, z;
+    __device__ explicit RayInv(V3<T> d) : x(d.x), y(d.y), z(d.z) {}
+    __device__ const Recip<T>& on(int axis) const { return axis == 0 ? z : (axis == 1 ? y : x); }  // XY -> z, XZ -> y, YZ -> x
+};
+template <class T, class Div>
+__device__ inline bool rect_hit(int axis, T a1, T a2, T b1, T b2, T k, V3<T> o, V3<T> d, const Div& inv_dk, T t_min, T t_max, T& t_out) {
+    const T ok = axis == 0 ? o.z : (axis == 1 ? o.y : o.x);
     const T oa = axis == 2 ? o.y : o.x, da = axis == 2 ? d.y : d.x;
     const T ob = axis == 0 ? o.y : o.z, db = axis == 0 ? d.y : d.z;
-    const T t = (k - ok) / dk;
+    const T t = inv_dk.div(k - ok);
     const T a = oa + t * da;
     const T b = ob + t * db;
     const bool hit = (t >= t_min) & (t <= t_max) & (a >= a1) & (a <= a2) & (b >= b1) & (b <= b2);  // inclusive
     t_out = hit ? t : t_out;
     return hit;
 }
+// `tie` (prim_hit, sphere_hit): set when a candidate distance EQUALS t_max exactly.  Equal distances are where the
+// outcome of a closest-hit search depends on the order of the tests (strict for spheres: the earlier one keeps the hit;
+// inclusive for rectangles: the later one takes it); walk_fast, which visits leaves in another order than
+// the reference, hands such rays to the reference-order walk.  Over-reporting is harmless.
 // src/objects.rs:87-119 / 160-193 (strict comparisons).  Both roots are evaluated; the first in
 // range wins, as in the reference.
 template <class T>
-__device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
+__device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out, bool& tie) {
     V3<T> oc = o - center;
     T a = dot(d, d);
     T half_b = dot(oc, d);
@@ -338,10 +415,12 @@ __device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_
     T discriminant = half_b * half_b - a * c;
     if (discriminant > T(0)) {
         T sq = sqrt_r(discriminant);
-        T r1 = (-half_b - sq) / a;
-        T r2 = (-half_b + sq) / a;
+        const Recip<T> inv_a(a);
+        T r1 = inv_a.div(-half_b - sq);
+        T r2 = inv_a.div(-half_b + sq);
         bool h1 = (r1 > t_min) & (r1 < t_max);
         bool h2 = (r2 > t_min) & (r2 < t_max);
+        tie = (r1 == t_max) | (r2 == t_max);
         if (h1 | h2) { t_out = h1 ? r1 : r2; return true; }
     }
     return false;
@@ -364,20 +443,24 @@ template <class T> __device__ inline void cuboid_side(const DPrim<T>& p, int i, 
 
 // Closest hit of ONE primitive in (t_min, t_max); side = cuboid face.
 template <class T, uint32_t F>
-__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t_min, T t_max, T& t_out, int& side) {
+__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side, bool& tie) {
     side = 0;
+    tie = false;
     const uint32_t kind = p.kind;
     if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && kind <= 1) {  // one sphere test for both kinds: mixed leaves stay converged
         V3<T> center(p.d);
         T radius = p.d[3];
         if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
-        return sphere_hit(center, radius, o, d, t_min, t_max, t_out);
+        return sphere_hit(center, radius, o, d, t_min, t_max, t_out, tie);
     }
     if (has<F>(F_RECT) && kind >= 2 && kind <= 4) {
         // one copy per axis behind a wave-uniform branch: with a run-time axis the six component picks are 12 selects
-        if (kind == 2) return rect_hit<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
-        if (kind == 3) return rect_hit<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
-        return rect_hit<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, t_min, t_max, t_out);
+        bool h;
+        if (kind == 2) h = rect_hit<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.z, t_min, t_max, t_out);
+        else if (kind == 3) h = rect_hit<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.y, t_min, t_max, t_out);
+        else h = rect_hit<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.x, t_min, t_max, t_out);
+        tie = h & (t_out == t_max);
+        return h;
     }
     if (has<F>(F_CUBOID) && kind == 5) {  // six sides in tuple order, shrinking closest (src/objects.rs:458-485)
         bool any = false;
@@ -387,13 +470,19 @@ __device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T t
             int axis; T a1, a2, b1, b2, k, face;
             cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
             T t = closest;
-            const bool h = rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, t_min, closest, t);
+            const bool h = rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, inv.on(axis), t_min, closest, t);
             any |= h; closest = t; side = h ? i : side;
         }
         t_out = closest;
+        tie = any & (closest == t_max);
         return any;
     }
     return false;
+}
+template <class T, uint32_t F>
+__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side) {
+    bool tie;
+    return prim_hit<T, F>(p, o, d, inv, time, t_min, t_max, t_out, side, tie);
 }
 
 // src/bvh.rs:26-58 — loose slab test, true divisions, minNum/maxNum; all three axes evaluated
@@ -413,6 +502,36 @@ template <class T> __device__ inline bool aabb_hit(const T* mn, const T* mx, V3<
         T t1 = (mn[2] - o.z) / d.z, t2 = (mx[2] - o.z) / d.z;
         const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
         ok &= !(rmin(t_max, hi) <= rmax(t_min, lo));
+    }
+    return ok;
+}
+
+// Does the reference's loose test of this box certainly PASS for every t_max it can be called with on the way to a
+// leaf whose accepted hit lies at t_win?  (walk_fast: the box is the leaf's parent node in the reference's tree.)
+// The reference passes axis a iff min(t_max, hi_a) > max(t_min, lo_a), with the slab ends computed as in aabb_hit, and
+// its t_max is the closest distance found so far: >= t_win, and > t_win when tmax_above (no equal distance anywhere).
+// Sufficient, per axis: hi_a > max(t_min, lo_a), t_win > t_min, and lo_a < t_win — or lo_a == t_win with tmax_above
+// (a hit ON the box face, the normal case for a cuboid whose face lies in its parent's box).  A NaN slab end (0/0) is
+// left to the exact emulation.
+template <class T> __device__ inline bool aabb_vouch(const T* mn, const T* mx, V3<T> o, V3<T> d, T t_min, T t_win, bool tmax_above) {
+    bool ok = t_win > t_min;
+    {
+        T t1 = (mn[0] - o.x) / d.x, t2 = (mx[0] - o.x) / d.x;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        const T m = lo > t_min ? lo : t_min;
+        ok &= (lo == lo) & (hi == hi) & (hi > m) & ((lo < t_win) | ((lo == t_win) & tmax_above));
+    }
+    {
+        T t1 = (mn[1] - o.y) / d.y, t2 = (mx[1] - o.y) / d.y;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        const T m = lo > t_min ? lo : t_min;
+        ok &= (lo == lo) & (hi == hi) & (hi > m) & ((lo < t_win) | ((lo == t_win) & tmax_above));
+    }
+    {
+        T t1 = (mn[2] - o.z) / d.z, t2 = (mx[2] - o.z) / d.z;
+        const bool sw = t1 > t2; const T lo = sw ? t2 : t1, hi = sw ? t1 : t2;
+        const T m = lo > t_min ? lo : t_min;
+        ok &= (lo == lo) & (hi == hi) & (hi > m) & ((lo < t_win) | ((lo == t_win) & tmax_above));
     }
     return ok;
 }
@@ -544,29 +663,28 @@ template <class T> struct Walk {
     T closest, t_min;
     bool any, leaf_cull;
     int prim, side;
+    float B;           // largest |coordinate| of the tree's root box
     RayF r;            // per-ray constants of the first-level box classification
-    RayR<T> r2;        // second level (f64 mode only)
 };
+// fast: the device's own tree (walk_fast); else the reference's tree (walk_run)
 template <class T, uint32_t F>
-__device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T> o, V3<T> d, T time, T t_min, T t_max, Walk<T>& w) {
+__device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T> o, V3<T> d, T time, T t_min, T t_max, Walk<T>& w, bool fast) {
     w.any = false;
     w.closest = t_max;
     w.t_min = t_min;
     w.prim = -1;
     w.side = 0;
-    w.i = sc.bvh_root_entry[geom_index];
+    w.i = fast ? sc.fast_root_entry[geom_index] : sc.bvh_root_entry[geom_index];
     float B;
     {
-        const DBvhLite& root = sc.bvh_lite[w.i];
+        const DBvhLite& root = fast ? sc.fast_lite[w.i] : sc.bvh_lite[w.i];
         w.end = root.skip;
         B = fabsf(root.mn[0]);
         B = fmaxf(B, fabsf(root.mn[1])); B = fmaxf(B, fabsf(root.mn[2]));
         B = fmaxf(B, fabsf(root.mx[0])); B = fmaxf(B, fabsf(root.mx[1])); B = fmaxf(B, fabsf(root.mx[2]));
     }
     ray_consts_f<T>(w.r, o, d, t_min, B);  // 2^-18 (|o| + B)|1/d|: f32 rounding of o, box, products
-    if (sizeof(T) == 8) {
-        ray_consts<T, T>(w.r2, o, d, t_min, (T)B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
-    }
+    w.B = B;
     // leaves carry their primitive's own box: most leaf visits are misses (measured 94 % in random_scene) and
     // an exact sphere / cuboid test costs 70-270 f64 instructions.  Moving spheres' boxes cover sc.time_lo..time_hi.
 #ifdef RT_DBG_NO_LEAF_CULL
@@ -582,10 +700,12 @@ __device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T
 //   B  undecided internal nodes: second level (f64), then the reference's exact test
 //   C  leaf primitive tests
 // The per-lane sequence of decisions is the sequential one; only the interleaving between lanes differs.
-// Node records come from LDS for the entries the render kernel staged there, else from global memory (L2).
+// Node records come from global memory (L2): the LDS copy the render kernels stage is of the device's own trees.
+// This is the EXACT EMULATION of the reference's traversal (order, box decisions in the grazing cases); the render
+// kernels run it only for the rays walk_fast could not vouch for.
 template <class T, uint32_t F>
-__device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, T time) {
-    const int n_lds = (int)sc.n_bvh_lds;
+__device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, const RayInv<T>& inv, T time) {
+    const int n_lds = 0;
     int i = w.i;
     const int end = w.end;
     T closest = w.closest;
@@ -620,9 +740,11 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
         if (undecided) {
             int c = 2;
             const DBvhEntry<T>& ex = sc.bvh[i];
-            if (sizeof(T) == 8) {  // second level: f64 ray against the exact box
+            if (sizeof(T) == 8) {  // second level: f64 ray against the exact box (its ray constants are built here: the step is rare)
                 RT_SIM_COUNT(5);
-                c = aabb_classify<T, T>(ex.mn, ex.mx, w.r2, closest, closest);
+                RayR<T> r2;
+                ray_consts<T, T>(r2, o, d, w.t_min, (T)w.B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products
+                c = aabb_classify<T, T>(ex.mn, ex.mx, r2, closest, closest);
             }
             bool pass = c == 1;
             if (c == 2) {  // rare: the reference's exact decision on the exact box
@@ -633,7 +755,7 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
         } else {
             T t; int side;
             RT_SIM_COUNT(2);
-            if (prim_hit<T, F>(sc.prims[prim], o, d, time, w.t_min, closest, t, side)) {
+            if (prim_hit<T, F>(sc.prims[prim], o, d, inv, time, w.t_min, closest, t, side)) {
                 RT_SIM_COUNT(3);
                 w.any = true; closest = t; w.prim = prim; w.side = side;
             }
@@ -648,17 +770,110 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
 #endif
 }
 
+// The walk the render kernels run first: over the device's OWN tree of the same leaves (surface-area heuristic,
+// rt_pack.hpp), with a two-way box decision.  Why the result is still the reference's, bit for bit:
+//  * Box decision.  A box is skipped only when nothing inside it can be hit in (t_min, closest) — the outer interval
+//    of aabb_classify_f, margins included — and entered otherwise.  Skipping is therefore harmless whatever the tree,
+//    and entering more boxes than the reference would only costs time: the leaves decide, with the exact tests.
+//    So this walk finds the closest of ALL hits the exact primitive tests accept.
+//  * The reference finds the closest of the hits IT reaches, and it can fail to reach a leaf: its loose slab test
+//    (bvh.rs:26-58) may reject, by rounding, a box whose primitive the exact test would accept (a ray grazing the box).
+//    A hit of this walk is vouched for when the loose test of the leaf's PARENT NODE IN THE REFERENCE'S TREE passes for
+//    every t_max the reference can use there (aabb_vouch): every ancestor box contains that box and the slab arithmetic
+//    is monotone in the bounds and in t_max, so all of the reference's box tests on the path to that leaf pass and it
+//    tests the leaf too (6 divisions, once per walk that hit something).
+//  * Order.  With distinct distances the closest accepted hit does not depend on the order of the tests; with EQUAL
+//    distances it does, and this walk visits leaves in another order: `tie` of prim_hit.
+//  Rays whose hit is not vouched for, or that met a tie, are walked again by walk_run (returns false).  f32 mode has no
+//  bit-exactness bar and skips both checks.
+template <class T, uint32_t F>
+__device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, const RayInv<T>& inv, T time) {
+    const int n_lds = (int)sc.n_bvh_lds;
+    int i = w.i;
+    const int end = w.end;
+    T closest = w.closest;
+    const T t_max0 = w.closest;  // the distance the search starts from (the closest hit of the instances before this one)
+    bool doubt = false;
+    int ref_parent = 0;
+    // per axis the bound the ray meets first: near = min for a positive direction (a bad ray never culls: the pick is irrelevant)
+    const bool px = w.r.ix >= 0.0f, py = w.r.iy >= 0.0f, pz = w.r.iz >= 0.0f;
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+    const unsigned long long sim_n0 = g_sim_counters[0];
+#endif
+    for (;;) {
+        int prim = -1;
+        float tmax_lo, tmax_hi;
+        widen<float>(to_f32_sat(closest), tmax_lo, tmax_hi);
+        RT_PCB();
+        DBvhLite e;
+        e.skip = end;
+        while (i != end) {
+            if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.fast_lite[i];
+            prim = e.prim;
+            // outer interval only: lo - e on the near bounds, hi + e on the far ones (see aabb_classify_f)
+            const float lox = fmaf(px ? e.mn[0] : e.mx[0], w.r.ix, w.r.kmx), hix = fmaf(px ? e.mx[0] : e.mn[0], w.r.ix, w.r.kpx);
+            const float loy = fmaf(py ? e.mn[1] : e.mx[1], w.r.iy, w.r.kmy), hiy = fmaf(py ? e.mx[1] : e.mn[1], w.r.iy, w.r.kpy);
+            const float loz = fmaf(pz ? e.mn[2] : e.mx[2], w.r.iz, w.r.kmz), hiz = fmaf(pz ? e.mx[2] : e.mn[2], w.r.iz, w.r.kpz);
+            const float out_lo = fmaxf(fmaxf(lox, loy), fmaxf(loz, w.r.tmin_lo));
+            const float out_hi = fminf(fminf(hix, hiy), fminf(hiz, tmax_hi));
+            const bool miss = !w.r.bad && (out_hi - out_lo < 0.0f);
+            RT_SIM_COUNT(0);
+            if (prim >= 0) {
+                if (!miss || !w.leaf_cull) break;  // a leaf that cannot be ruled out is tested
+                RT_SIM_COUNT(4);
+                i = i + 1;
+                continue;
+            }
+            i = miss ? e.skip : i + 1;
+        }
+        RT_PCE(2);
+        if (i == end) break;
+        T t; int side; bool tie;
+        const bool any_before = w.any;
+        RT_SIM_COUNT(2);
+        if (prim_hit<T, F>(sc.prims[prim], o, d, inv, time, w.t_min, closest, t, side, tie)) {
+            RT_SIM_COUNT(3);
+            w.any = true; closest = t; w.prim = prim; w.side = side;
+            ref_parent = e.skip;  // a leaf's skip field: its parent node's entry in the reference's tree
+        }
+        if (sizeof(T) == 8 && tie && any_before) doubt = true;  // equal to a distance found in THIS walk: order decides
+        i = i + 1;
+        RT_PCE(3);
+    }
+    w.i = i;
+    w.closest = closest;
+    if (sizeof(T) == 8 && w.any && !doubt) {
+        RT_SIM_COUNT(7);
+        const DBvhEntry<T>& pb = sc.bvh[ref_parent];
+        if (!aabb_vouch(pb.mn, pb.mx, o, d, w.t_min, closest, closest < t_max0)) doubt = true;
+    }
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+    RT_SIM_WALK(sim_n0);
+#endif
+    return !doubt;
+}
+
 // Geometry of an instance: one primitive, or a complete BVH walk.
 template <class T, uint32_t F>
-__device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, T time,
+__device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, const RayInv<T>& inv, T time,
                                 T t_min, T t_max, T& t_out, int& prim_out, int& side_out) {
     if (!has<F>(F_BVH) || geom_kind == 0) {
         prim_out = (int)geom_index;
-        return prim_hit<T, F>(sc.prims[geom_index], o, d, time, t_min, t_max, t_out, side_out);
+        return prim_hit<T, F>(sc.prims[geom_index], o, d, inv, time, t_min, t_max, t_out, side_out);
     }
     Walk<T> w;
-    walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w);
-    walk_run<T, F>(sc, w, o, d, time);
+    bool sure = false;
+#ifndef RT_NO_FAST_WALK
+    if (time >= sc.time_lo && time <= sc.time_hi) {  // (the device's trees are built from boxes valid for these ray times)
+        walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, true);
+        sure = walk_fast<T, F>(sc, w, o, d, inv, time);
+    }
+#endif
+    if (!sure) {
+        RT_SIM_COUNT(6);
+        walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, false);
+        walk_run<T, F>(sc, w, o, d, inv, time);
+    }
     if (w.any) { prim_out = w.prim; side_out = w.side; }
     t_out = w.closest;
     return w.any;
@@ -667,8 +882,10 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
 // src/transforms.rs:15-17, 90-103: world ray -> object ray through the instance's wrapper chain.
 // transforms.rs:34-39,124-135: pdf_value / random forward the origin (and the direction through
 // RotateY) the same way.
-template <class T, uint32_t F> __device__ inline void xform_ray(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
-    if (!has<F>(F_XFORM)) return;
+// Returns whether the direction changed (a RotateY in the chain): the caller's shared reciprocals of d then need renewing.
+template <class T, uint32_t F> __device__ inline bool xform_ray(const DScene<T>& sc, const DInstance<T>& in, V3<T>& o, V3<T>& d) {
+    if (!has<F>(F_XFORM)) return false;
+    bool rotated = false;
     for (uint32_t j = 0; j < in.xform_count; j++) {
         const DXform<T>& x = sc.xforms[in.xform_begin + j];
         if (x.kind == 0) {
@@ -677,8 +894,10 @@ template <class T, uint32_t F> __device__ inline void xform_ray(const DScene<T>&
             T s = x.v[0], c = x.v[1];
             o = V3<T>(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
             d = V3<T>(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+            rotated = true;
         }
     }
+    return rotated;
 }
 // src/transforms.rs:18-21, 105-116: hit record back to world space (innermost wrapper first)
 template <class T, uint32_t F> __device__ inline void xform_back(const DScene<T>& sc, const DInstance<T>& in, V3<T>& p, V3<T>& n) {
@@ -737,10 +956,15 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             if (nan) return false;  // (chk is also NaN for inf - inf: those rays take the normal route)
         }
     }
+    // rectangle tests divide by a direction component: the reciprocal part of those divisions is shared per axis (Recip)
+    constexpr bool kRects = has<F>(F_RECT) || has<F>(F_CUBOID);
+    const RayInv<T> inv_world(kRects ? ray.dir : V3<T>(T(1), T(1), T(1)));
     for (uint32_t i = 0; i < sc.n_world; i++) {
         const DInstance<T>& in = sc.world[i];
         V3<T> o = ray.ori, d = ray.dir;
-        xform_ray<T, F>(sc, in, o, d);
+        const bool rotated = xform_ray<T, F>(sc, in, o, d);
+        RayInv<T> inv = inv_world;
+        if (kRects && rotated) { inv.x = Recip<T>(d.x); inv.z = Recip<T>(d.z); }  // RotateY keeps d.y (wave-uniform branch)
         const bool med = has<F>(F_MEDIUM) && in.is_medium;
         T ta = T(0);
         const int passes = med ? 2 : 1;
@@ -749,7 +973,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             const T lo = med ? (pass == 0 ? -Lim<T>::max() : ta + T(0.0001)) : t_min;
             const T hi = med ? Lim<T>::max() : closest;
             T t = hi; int prim = -1, side = 0;
-            const bool h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, ray.time, lo, hi, t, prim, side);
+            const bool h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, lo, hi, t, prim, side);
             if (!med) {
                 if (h) { any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side; }
             } else if (has<F>(F_MEDIUM)) {

@@ -86,6 +86,8 @@ int build_device_scene(RtScene* sc, const RtSceneDesc* d, const rt::DImage* d_im
     if ((rc = upload(sc, h.bvh, &out.bvh))) return rc;
     if ((rc = upload(sc, h.bvh_root_entry, &out.bvh_root_entry))) return rc;
     if ((rc = upload(sc, h.bvh_lite, &out.bvh_lite))) return rc;
+    if ((rc = upload(sc, h.fast_lite, &out.fast_lite))) return rc;
+    if ((rc = upload(sc, h.fast_root_entry, &out.fast_root_entry))) return rc;
     out.images = d_images;
     return RT_OK;
 }
@@ -321,6 +323,15 @@ int rt_debug_sample_pixel(RtScene* scene, const RtRenderParams* params, uint32_t
     if (params->precision == RT_F64) HIP_TRY(rt::launch_sample_pixel<double>(scene->s64, scene->features, a, x, y, a.spp_count, d_out, (hipStream_t)stream));
     else if (params->precision == RT_F32) HIP_TRY(rt::launch_sample_pixel<float>(scene->s32, scene->features, a, x, y, a.spp_count, d_out, (hipStream_t)stream));
     else return fail(RT_ERR_INVALID, "unknown precision");
+    return RT_OK;
+}
+
+/* Test hook: d_shared[i] = n[i] / d[i] by the shared-denominator route of rt_device.hpp (Recip), d_plain[i] by `/`. */
+int rt_debug_divide(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, void* stream) {
+    if (!d_n || !d_d || !d_shared || !d_plain) return fail(RT_ERR_INVALID, "NULL buffer");
+    if (count == 0) return RT_OK;
+    if (count > 0xffffffffull * 256ull) return fail(RT_ERR_INVALID, "count too large");
+    HIP_TRY(rt::launch_divide_check(d_n, d_d, count, d_shared, d_plain, (hipStream_t)stream));
     return RT_OK;
 }
 

@@ -1,3 +1,20 @@
 // f64 instantiation: compile with -ffp-contract=off (see build.py).
 #define RT_REAL double
 #include "rt_kernels.inc"
+
+namespace rt {
+// Test hook (rt_debug_divide): quotients by the shared-denominator route (Recip<double>, three numerators per
+// denominator as unit() uses it) and by the plain `/`, for a bit-for-bit comparison on the device.
+__global__ void divide_check_kernel(const double* __restrict__ n, const double* __restrict__ d, uint64_t count, double* __restrict__ shared,
+                                    double* __restrict__ plain) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const SharedRecip<double> r(d[i]);
+    shared[i] = r.div(n[i]);
+    plain[i] = n[i] / d[i];
+}
+hipError_t launch_divide_check(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, hipStream_t stream) {
+    hipLaunchKernelGGL(divide_check_kernel, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, d_n, d_d, count, d_shared, d_plain);
+    return hipGetLastError();
+}
+}  // namespace rt

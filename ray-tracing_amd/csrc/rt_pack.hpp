@@ -2,6 +2,7 @@
 // converts it into the device record layouts of rt_device.hpp (in host vectors; rt_hip.hip uploads
 // them).  No HIP calls here, so tests/hostsim can run the same packing on the CPU.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -21,9 +22,11 @@ template <class T> struct PackedScene {
     std::vector<DPerlin<T>> perlins;
     std::vector<DXform<T>> xforms;
     std::vector<DInstance<T>> world, lights;
-    std::vector<DBvhEntry<T>> bvh;
+    std::vector<DBvhEntry<T>> bvh;        // the reference's trees, threaded (exact boxes)
     std::vector<int32_t> bvh_root_entry;
     std::vector<DBvhLite> bvh_lite;
+    std::vector<DBvhLite> fast_lite;      // the device's own trees over the same leaves (SAH), threaded
+    std::vector<int32_t> fast_root_entry;
     DScene<T> view;  // scalars filled by pack_scene; pointers by whoever owns the memory
 };
 
@@ -185,6 +188,143 @@ void thread_bvh(const RtBvh& b, int32_t node, std::vector<DBvhEntry<T>>& out, st
     }
 }
 
+// Conservative f64 box of a primitive over the ray times [time_lo, time_hi] (spheres: centre -+ |r|; moving spheres:
+// hull of the two end positions, padded for the rounding of the centre arithmetic; rects padded by 1e-4 on the thin
+// axis as objects.rs:245-250 does).  Used for the leaf entries' cull boxes and for the device's own trees.
+inline void prim_cull_box(const RtPrim& p, double time_lo, double time_hi, double mn[3], double mx[3]) {
+    const double big = 1e300;
+    switch (p.kind) {
+        case RT_PRIM_SPHERE: {
+            double r = std::fabs(p.d[3]);
+            for (int k = 0; k < 3; k++) { mn[k] = p.d[k] - r; mx[k] = p.d[k] + r; }
+            break;
+        }
+        case RT_PRIM_MOVING_SPHERE: {
+            double r = std::fabs(p.d[8]), den = p.d[7] - p.d[6];
+            for (int k = 0; k < 3; k++) {
+                double c0 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_lo - p.d[6]) / den);
+                double c1 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_hi - p.d[6]) / den);
+                double pad = 1e-9 * (std::fabs(c0) + std::fabs(c1) + r + 1.0);  // centre arithmetic rounding
+                mn[k] = std::fmin(c0, c1) - r - pad; mx[k] = std::fmax(c0, c1) + r + pad;
+                if (!(mn[k] == mn[k]) || !(mx[k] == mx[k])) { mn[k] = -big; mx[k] = big; }
+            }
+            break;
+        }
+        case RT_PRIM_CUBOID:
+            for (int k = 0; k < 3; k++) { mn[k] = std::fmin(p.d[k], p.d[3 + k]); mx[k] = std::fmax(p.d[k], p.d[3 + k]); }
+            break;
+        default: {  // rects: a1,a2,b1,b2,k
+            int axis = (int)p.kind - RT_PRIM_RECT_XY;  // 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x)
+            int ia = axis == 2 ? 1 : 0, ib = axis == 0 ? 1 : 2, ik = 2 - axis;
+            mn[ia] = std::fmin(p.d[0], p.d[1]); mx[ia] = std::fmax(p.d[0], p.d[1]);
+            mn[ib] = std::fmin(p.d[2], p.d[3]); mx[ib] = std::fmax(p.d[2], p.d[3]);
+            mn[ik] = p.d[4] - 0.0001; mx[ik] = p.d[4] + 0.0001;
+        }
+    }
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(mn[k]) || !std::isfinite(mx[k])) { mn[k] = -big; mx[k] = big; }
+}
+
+// The device's own tree over the leaves of one reference tree: surface-area heuristic (full sweep up to 32 leaves,
+// 16 bins above), written as RtBvh-style SoA rows in pre-order so that thread_bvh() serves both kinds of tree.
+// The reference builds with a random split axis and a median split (bvh.rs:85-111); a ray visits ~30 % fewer nodes
+// of a SAH tree (measured with tools/sim_counters.py: random_scene 32.9 -> 23.8, final_scene 21.5 -> 14.9 per cast).
+// WHICH primitive is hit does not depend on the tree: see walk_fast() in rt_device.hpp.
+struct SahTree {
+    std::vector<double> box[6];
+    std::vector<int32_t> left, right;
+    int32_t add() { for (auto& b : box) b.push_back(0.0); left.push_back(0); right.push_back(0); return (int32_t)left.size() - 1; }
+};
+struct SahBox {
+    double mn[3], mx[3];
+    void reset() { for (int k = 0; k < 3; k++) { mn[k] = 1e308; mx[k] = -1e308; } }
+    void grow(const double* a, const double* b) { for (int k = 0; k < 3; k++) { mn[k] = std::fmin(mn[k], a[k]); mx[k] = std::fmax(mx[k], b[k]); } }
+    double area() const {
+        double e[3];
+        for (int k = 0; k < 3; k++) { e[k] = mx[k] - mn[k]; if (!(e[k] > 0.0)) e[k] = 0.0; if (e[k] > 1e150) e[k] = 1e150; }
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+};
+struct SahLeaf { int32_t prim, ref_parent; double mn[3], mx[3], c[3]; };
+inline int32_t sah_build(std::vector<SahLeaf>& leaves, size_t lo, size_t hi, SahTree& out, int depth) {
+    // leaves[lo, hi), hi - lo >= 2; returns the node index
+    const int32_t me = out.add();
+    SahBox all; all.reset();
+    SahBox cb; cb.reset();
+    for (size_t i = lo; i < hi; i++) { all.grow(leaves[i].mn, leaves[i].mx); cb.grow(leaves[i].c, leaves[i].c); }
+    for (int k = 0; k < 3; k++) { out.box[k][me] = all.mn[k]; out.box[3 + k][me] = all.mx[k]; }
+    const size_t n = hi - lo;
+    size_t mid = lo + n / 2;
+    int best_axis = -1;
+    if (depth < 48) {
+        double best = 1e308;
+        if (n <= 32) {  // full sweep on every axis
+            std::vector<SahLeaf> tmp(leaves.begin() + lo, leaves.begin() + hi), keep;
+            std::vector<double> right_area(n);
+            for (int ax = 0; ax < 3; ax++) {
+                std::stable_sort(tmp.begin(), tmp.end(), [ax](const SahLeaf& a, const SahLeaf& b) { return a.c[ax] < b.c[ax]; });
+                SahBox b; b.reset();
+                for (size_t i = n; i-- > 1;) { b.grow(tmp[i].mn, tmp[i].mx); right_area[i] = b.area(); }
+                b.reset();
+                for (size_t i = 1; i < n; i++) {
+                    b.grow(tmp[i - 1].mn, tmp[i - 1].mx);
+                    const double cost = b.area() * (double)i + right_area[i] * (double)(n - i);
+                    if (cost < best) { best = cost; best_axis = ax; mid = lo + i; keep = tmp; }
+                }
+            }
+            if (best_axis >= 0) std::copy(keep.begin(), keep.end(), leaves.begin() + lo);
+        } else {        // 16 bins on the centroid range of every axis
+            constexpr int NB = 16;
+            double best_split = 0.0;
+            for (int ax = 0; ax < 3; ax++) {
+                const double c0 = cb.mn[ax], c1 = cb.mx[ax];
+                if (!(c1 > c0)) continue;
+                const double scale = NB / (c1 - c0);
+                SahBox bins[NB]; size_t cnt[NB] = {0};
+                for (auto& b : bins) b.reset();
+                for (size_t i = lo; i < hi; i++) {
+                    int bi = (int)((leaves[i].c[ax] - c0) * scale);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    bins[bi].grow(leaves[i].mn, leaves[i].mx); cnt[bi]++;
+                }
+                double ra[NB]; size_t rc[NB];
+                SahBox b; b.reset(); size_t c = 0;
+                for (int k = NB - 1; k >= 1; k--) { if (cnt[k]) b.grow(bins[k].mn, bins[k].mx); c += cnt[k]; ra[k] = c ? b.area() : 0.0; rc[k] = c; }
+                b.reset(); c = 0;
+                for (int k = 1; k < NB; k++) {
+                    if (cnt[k - 1]) b.grow(bins[k - 1].mn, bins[k - 1].mx);
+                    c += cnt[k - 1];
+                    if (c == 0 || rc[k] == 0) continue;
+                    const double cost = b.area() * (double)c + ra[k] * (double)rc[k];
+                    if (cost < best) { best = cost; best_axis = ax; best_split = c0 + (double)k / scale; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int ax = best_axis;
+                // recompute bin membership exactly as above for the partition
+                const double c0 = cb.mn[ax], scale = NB / (cb.mx[ax] - c0);
+                const int ksplit = (int)std::lround((best_split - c0) * scale);
+                auto it = std::stable_partition(leaves.begin() + lo, leaves.begin() + hi, [&](const SahLeaf& l) {
+                    int bi = (int)((l.c[ax] - c0) * scale);
+                    bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+                    return bi < ksplit;
+                });
+                mid = (size_t)(it - leaves.begin());
+                if (mid == lo || mid == hi) { best_axis = -1; mid = lo + n / 2; }
+            }
+        }
+    }
+    if (best_axis < 0) {  // all centroids equal / too deep: median split in the given order
+        mid = lo + n / 2;
+    }
+    // children in pre-order: node, left subtree, right subtree (RtBvh convention)
+    // (a leaf child is the complement of its final position in `leaves`: ranges of one element do not move any more)
+    const int32_t l = (mid - lo == 1) ? ~(int32_t)lo : sah_build(leaves, lo, mid, out, depth + 1);
+    const int32_t r = (hi - mid == 1) ? ~(int32_t)mid : sah_build(leaves, mid, hi, out, depth + 1);
+    out.left[me] = l; out.right[me] = r;
+    return me;
+}
+
 template <class T> void convert_instances(const RtInstance* ins, uint32_t n, std::vector<DInstance<T>>& out) {
     for (uint32_t i = 0; i < n; i++) {
         DInstance<T> o;
@@ -309,50 +449,74 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     const double time_lo = std::fmin(0.0, d->camera.t1), time_hi = std::fmax(1.0, d->camera.t2);
     auto down = [](double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; };
     auto up = [](double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; };
-    for (const DBvhEntry<T>& e : h.bvh) {
+    auto lite_of = [&](const DBvhEntry<T>& e, const double* nmn, const double* nmx) {
         DBvhLite l;
         double mn[3], mx[3];
-        if (e.prim < 0) {
-            for (int k = 0; k < 3; k++) { mn[k] = (double)e.mn[k]; mx[k] = (double)e.mx[k]; }
-        } else {
-            const RtPrim& p = d->prims[e.prim];
-            const double big = 1e300;
-            switch (p.kind) {
-                case RT_PRIM_SPHERE: {
-                    double r = std::fabs(p.d[3]);
-                    for (int k = 0; k < 3; k++) { mn[k] = p.d[k] - r; mx[k] = p.d[k] + r; }
-                    break;
-                }
-                case RT_PRIM_MOVING_SPHERE: {
-                    double r = std::fabs(p.d[8]), den = p.d[7] - p.d[6];
-                    for (int k = 0; k < 3; k++) {
-                        double c0 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_lo - p.d[6]) / den);
-                        double c1 = p.d[k] + (p.d[3 + k] - p.d[k]) * ((time_hi - p.d[6]) / den);
-                        double pad = 1e-9 * (std::fabs(c0) + std::fabs(c1) + r + 1.0);  // centre arithmetic rounding
-                        mn[k] = std::fmin(c0, c1) - r - pad; mx[k] = std::fmax(c0, c1) + r + pad;
-                        if (!(mn[k] == mn[k]) || !(mx[k] == mx[k])) { mn[k] = -big; mx[k] = big; }
-                    }
-                    break;
-                }
-                case RT_PRIM_CUBOID:
-                    for (int k = 0; k < 3; k++) { mn[k] = std::fmin(p.d[k], p.d[3 + k]); mx[k] = std::fmax(p.d[k], p.d[3 + k]); }
-                    break;
-                default: {  // rects: a1,a2,b1,b2,k  (objects.rs:245-250 pads the thin axis by 1e-4; so do we)
-                    int axis = (int)p.kind - RT_PRIM_RECT_XY;  // 0: XY (k on z), 1: XZ (k on y), 2: YZ (k on x)
-                    int ia = axis == 2 ? 1 : 0, ib = axis == 0 ? 1 : 2, ik = 2 - axis;
-                    mn[ia] = std::fmin(p.d[0], p.d[1]); mx[ia] = std::fmax(p.d[0], p.d[1]);
-                    mn[ib] = std::fmin(p.d[2], p.d[3]); mx[ib] = std::fmax(p.d[2], p.d[3]);
-                    mn[ik] = p.d[4] - 0.0001; mx[ik] = p.d[4] + 0.0001;
-                }
-            }
-        }
+        if (e.prim < 0) { for (int k = 0; k < 3; k++) { mn[k] = nmn[k]; mx[k] = nmx[k]; } }
+        else prim_cull_box(d->prims[e.prim], time_lo, time_hi, mn, mx);
         for (int k = 0; k < 3; k++) { l.mn[k] = down(mn[k]); l.mx[k] = up(mx[k]); }
         l.skip = e.skip; l.prim = e.prim;
-        h.bvh_lite.push_back(l);
+        return l;
+    };
+    for (const DBvhEntry<T>& e : h.bvh) {
+        double mn[3], mx[3];
+        for (int k = 0; k < 3; k++) { mn[k] = (double)e.mn[k]; mx[k] = (double)e.mx[k]; }
+        h.bvh_lite.push_back(lite_of(e, mn, mx));
+    }
+    // the device's own trees: one per reference tree that an instance uses, over the same leaves
+    // A leaf entry of such a tree carries, in `skip` (a leaf's successor is always the next entry), the entry of its
+    // PARENT NODE IN THE REFERENCE'S TREE: walk_fast validates a hit against that node's exact box.
+    h.fast_root_entry.assign(d->bvh.n_nodes, -1);
+    {
+        SahTree sah;
+        std::vector<SahLeaf> all_leaves;
+        std::vector<std::pair<uint32_t, int32_t>> roots;  // (reference root node, SAH root node)
+        auto build_for = [&](const RtInstance* ins, uint32_t n) {
+            for (uint32_t i = 0; i < n; i++) {
+                if (ins[i].geom_kind != RT_GEOM_BVH) continue;
+                const uint32_t ref_root = ins[i].geom_index;
+                bool seen = false;
+                for (auto& r : roots) seen |= r.first == ref_root;
+                if (seen) continue;
+                const size_t first = all_leaves.size();
+                const int32_t e0 = h.bvh_root_entry[ref_root], e1 = h.bvh[e0].skip;
+                std::vector<int32_t> open;  // internal entries whose subtree is not finished: the innermost is the parent
+                for (int32_t e = e0; e < e1; e++) {
+                    while (!open.empty() && h.bvh[open.back()].skip <= e) open.pop_back();
+                    if (h.bvh[e].prim < 0) { open.push_back(e); continue; }
+                    SahLeaf l; l.prim = h.bvh[e].prim; l.ref_parent = open.back();
+                    prim_cull_box(d->prims[l.prim], time_lo, time_hi, l.mn, l.mx);
+                    for (int k = 0; k < 3; k++) l.c[k] = 0.5 * (l.mn[k] + l.mx[k]);
+                    all_leaves.push_back(l);
+                }
+                // (a tree's root is an internal node with two children: >= 2 leaves)
+                roots.push_back({ref_root, sah_build(all_leaves, first, all_leaves.size(), sah, 0)});
+            }
+        };
+        build_for(d->world, d->n_world);
+        build_for(d->lights, d->n_lights);
+        if (!roots.empty()) {
+            RtBvh fb;
+            fb.n_nodes = (uint32_t)sah.left.size();
+            fb.min_x = sah.box[0].data(); fb.min_y = sah.box[1].data(); fb.min_z = sah.box[2].data();
+            fb.max_x = sah.box[3].data(); fb.max_y = sah.box[4].data(); fb.max_z = sah.box[5].data();
+            fb.left = sah.left.data(); fb.right = sah.right.data();
+            std::vector<DBvhEntry<double>> entries;
+            std::vector<int32_t> root_entry(fb.n_nodes, -1);
+            for (auto& r : roots) {
+                thread_bvh<double>(fb, r.second, entries, root_entry);
+                h.fast_root_entry[r.first] = root_entry[r.second];
+            }
+            for (const DBvhEntry<double>& e : entries) {
+                DBvhEntry<T> et; et.prim = e.prim; et.skip = e.skip;
+                if (e.prim >= 0) { et.prim = all_leaves[e.prim].prim; et.skip = all_leaves[e.prim].ref_parent; }
+                h.fast_lite.push_back(lite_of(et, e.mn, e.mx));
+            }
+        }
     }
     DScene<T>& out = h.view;
     out.time_lo = (T)time_lo; out.time_hi = (T)time_hi;
-    out.n_bvh = (uint32_t)h.bvh.size();
+    out.n_bvh = (uint32_t)h.fast_lite.size();
     out.n_bvh_lds = 0;
     out.bvh_lds = nullptr;
     out.n_perlins = d->n_perlins;

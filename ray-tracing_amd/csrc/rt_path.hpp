@@ -14,7 +14,8 @@ namespace rt {
 template <class T>
 __device__ inline T rect_pdf(int axis, T a1, T a2, T b1, T b2, T k, T face, V3<T> o, V3<T> v) {
     T t = T(0);
-    if (rect_hit<T>(axis, a1, a2, b1, b2, k, o, v, T(0.001), Lim<T>::max(), t)) {
+    const T vk = axis == 0 ? v.z : (axis == 1 ? v.y : v.x);
+    if (rect_hit<T>(axis, a1, a2, b1, b2, k, o, v, PlainDiv<T>(vk), T(0.001), Lim<T>::max(), t)) {
         const T z0 = T(0) * face;
         V3<T> normal(axis == 2 ? face : z0, axis == 1 ? face : z0, axis == 0 ? face : z0);
         T area = (a2 - a1) * (b2 - b1);
@@ -31,7 +32,8 @@ template <class T, uint32_t F> __device__ inline T prim_pdf_value(const DPrim<T>
         T t;
         V3<T> center(p.d);
         T radius = p.d[3];
-        if (sphere_hit(center, radius, o, v, T(0.001), Lim<T>::max(), t)) {
+        bool tie;
+        if (sphere_hit(center, radius, o, v, T(0.001), Lim<T>::max(), t, tie)) {
             T cos_theta_max = sqrt_r(T(1) - radius * radius / sqlen(center - o));
             T solid_angle = T(2) * Consts<T>::pi() * (T(1) - cos_theta_max);
             return T(1) / solid_angle;

@@ -1,0 +1,67 @@
+"""The device path's shared-denominator division (ray-tracing_amd/csrc/rt_device.hpp: Recip<double>) must be IEEE
+division: bit for bit equal to the compiler's `/` on the device AND to the host's correctly rounded quotient (numpy),
+for ordinary operands, for the operand ranges the path produces, and for every special case (zeros, subnormals,
+huge, infinities, NaN), where the routine falls back to `/`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from ray_tracing_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+def run(n, d):
+    n = torch.from_numpy(np.ascontiguousarray(n, dtype=np.float64)).cuda()
+    d = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float64)).cuda()
+    shared = torch.empty_like(n)
+    plain = torch.empty_like(n)
+    rc = _ffi.hip().rt_debug_divide(C.c_void_p(n.data_ptr()), C.c_void_p(d.data_ptr()), n.numel(), C.c_void_p(shared.data_ptr()),
+                                    C.c_void_p(plain.data_ptr()), None)
+    assert rc == 0, _ffi.hip().rt_last_error()
+    torch.cuda.synchronize()
+    return shared.cpu().numpy(), plain.cpu().numpy()
+
+
+def same_bits(a, b):
+    a, b = a.view(np.uint64), b.view(np.uint64)
+    nan = np.isnan(a.view(np.float64)) & np.isnan(b.view(np.float64))  # any NaN payload equals any NaN
+    return (a == b) | nan
+
+
+def test_shared_reciprocal_division_is_ieee_division(gpu):
+    rs = np.random.RandomState(7)
+    N = 1 << 22
+    cases = []
+    # ordinary magnitudes (scene coordinates, directions, lengths)
+    cases.append((rs.uniform(-1000, 1000, N), rs.uniform(-2, 2, N)))
+    cases.append((rs.standard_normal(N) * 555.0, rs.standard_normal(N)))
+    # random bit patterns over the whole exponent range (includes subnormals, inf, NaN)
+    cases.append((rs.randint(0, 2 ** 63, N, dtype=np.int64).view(np.float64) * rs.choice([-1.0, 1.0], N),
+                  rs.randint(0, 2 ** 63, N, dtype=np.int64).view(np.float64)))
+    # mantissa edge cases at moderate exponents: all-ones / all-zeros mantissas, neighbours of powers of two
+    m = np.array([0x0, 0x1, 0xFFFFFFFFFFFFF, 0xFFFFFFFFFFFFE, 0x8000000000000, 0x7FFFFFFFFFFFF, 0x5555555555555, 0xAAAAAAAAAAAAA], dtype=np.uint64)
+    e = np.arange(1023 - 405, 1023 + 406, 1, dtype=np.uint64)  # across both guard edges (2^-400, 2^400)
+    grid = ((e[:, None] << np.uint64(52)) | m[None, :]).reshape(-1).view(np.float64)
+    gn, gd = np.meshgrid(grid[::7], grid[::5])
+    cases.append((gn.reshape(-1), gd.reshape(-1)))
+    # specials against everything
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, -1.7976931348623157e308,
+                   1.0, -1.0, 3.0, 1e-300, 1e300, 2.0 ** -400, 2.0 ** 400, np.nextafter(2.0 ** -400, 0), np.nextafter(2.0 ** 400, np.inf)])
+    sn, sd = np.meshgrid(sp, sp)
+    cases.append((sn.reshape(-1), sd.reshape(-1)))
+    # the hot call sites' shapes: (k - o)/d for planes, v/len(v) for unit vectors, roots/a
+    o = rs.uniform(-800, 800, N); k = rs.choice([0.0, 555.0, 554.0, 165.0, 330.0], N); dd = rs.standard_normal(N) * rs.choice([1.0, 1e-3, 1e-9, 400.0], N)
+    cases.append((k - o, dd))
+    v = rs.standard_normal((N, 3)); ln = np.sqrt((v * v).sum(1))
+    cases.append((v[:, 0], ln))
+    with np.errstate(all="ignore"):
+        for n, d in cases:
+            shared, plain = run(n, d)
+            want = n / d  # host IEEE division, correctly rounded
+            assert same_bits(shared, plain).all(), "shared-denominator quotient differs from the device's `/`"
+            ok = same_bits(shared, want)
+            # the device flushes nothing and rounds correctly; the only tolerated difference is none
+            assert ok.all(), (n[~ok][:4], d[~ok][:4], shared[~ok][:4], want[~ok][:4])

@@ -21,6 +21,9 @@ cd "$REPO"
 PYT="python -u -m pytest -x -v --timeout 240 --timeout-method thread"
 for w in $WHAT; do
 case $w in
+div) step pytest_div 300 $PYT tests/test_gpu_divide.py > "$OUT/pytest_div.log" 2>&1 || { tail -40 "$OUT/pytest_div.log"; exit 1; }; tail -3 "$OUT/pytest_div.log";;
+scenes) step scenes 1100 bash tools/gpu_scenes.sh $TAG > "$OUT/scenes.txt" 2> "$OUT/scenes.err" || { tail -20 "$OUT/scenes.err"; exit 1; }; cat "$OUT/scenes.txt";;
+benchq) step benchq 600 python -u bench.py --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/benchq.json" 2> "$OUT/benchq.err" || { tail -20 "$OUT/benchq.err"; exit 1; }; cat "$OUT/benchq.json";;
 new) step pytest_new 600 $PYT tests/test_gpu_round2.py > "$OUT/pytest_new.log" 2>&1 || { tail -40 "$OUT/pytest_new.log"; exit 1; }; tail -3 "$OUT/pytest_new.log";;
 wip) step pytest_wip 300 $PYT tests/test_zz_no_alloc.py > "$OUT/pytest_wip.log" 2>&1 || { tail -40 "$OUT/pytest_wip.log"; exit 1; }; tail -3 "$OUT/pytest_wip.log";;
 all) step pytest_gpu 1000 $PYT tests -m gpu > "$OUT/pytest_gpu.log" 2>&1 || { tail -40 "$OUT/pytest_gpu.log"; exit 1; }; tail -3 "$OUT/pytest_gpu.log";;

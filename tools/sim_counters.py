@@ -40,7 +40,7 @@ for precision in ("f64", "f32"):
     L.sim_render(h, C.byref(p), 0, acc.ctypes.data, C.byref(casts))
     n = max(casts.value, 1)
     names = ["node classifications (level 1)", "exact box tests", "leaf primitive tests", "leaf hits", "leaves culled by their box",
-             "level-2 classifications"]
+             "level-2 classifications", "reference-order walks (fallback)", "hit validations (parent box, exact)"]
     print(f"{name} {W}x{H}@{spp} {precision}: {casts.value} casts")
     for i, nm in enumerate(names):
         print(f"  {nm:34s} {ctr[i] / n:9.3f} per cast")
