@@ -118,6 +118,7 @@ template <class T> struct DScene {
     uint32_t n_bvh, n_bvh_lds;      // n_bvh: entries of fast_lite (= of bvh: same leaves, same number of internal nodes)
     const DPerlin<T>* perlin_lds;     // perlins [0, n_perlin_lds) staged in LDS by the render kernel (else n_perlin_lds = 0)
     uint32_t n_perlins, n_perlin_lds;
+    unsigned long long* tex_cache;    // -DRT_TEX_LDS_CACHE=<entries> builds: LDS texel cache of the render kernel (else unused)
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
     uint32_t n_world, n_lights, n_materials;
     T background[3];
@@ -1170,8 +1171,26 @@ template <class T, uint32_t F> __device__ inline V3<T> texture_value(const DScen
                 if (x > im.width - 1) x = im.width - 1;
                 uint32_t y = as_u32(vc * (T)im.height);
                 if (y > im.height - 1) y = im.height - 1;
-                const uint8_t* px = im.rgb + ((size_t)(im.height - 1 - y) * im.width + x) * 3;
+                const size_t texel = (size_t)(im.height - 1 - y) * im.width + x;
                 T color_scale = T(1) / T(255);
+#if defined(RT_TEX_LDS_CACHE) && defined(__HIP_DEVICE_COMPILE__) && !defined(RT_HOST_SIM)
+                // EXPERIMENT (profiles/r02_texture_tiles.md): texels through a direct-mapped cache in LDS shared by the block.
+                // An entry is one 8-byte word {tag = image, texel index + 1 | rgb}: written and read whole, so a racing
+                // refill by another wave leaves either the old or the new pair, both consistent.
+                if (sc.tex_cache) {
+                    typedef __attribute__((address_space(3))) unsigned long long* lds_u64;
+                    const uint32_t tag = (uint32_t)texel + 1u + (t.table << 26);
+                    lds_u64 slot = (lds_u64)(uintptr_t)(uint32_t)(uintptr_t)sc.tex_cache + (((uint32_t)texel ^ ((uint32_t)texel >> 10)) & (uint32_t)(RT_TEX_LDS_CACHE - 1));
+                    unsigned long long ent = *slot;
+                    if ((uint32_t)(ent >> 32) != tag) {
+                        const uint8_t* px = im.rgb + texel * 3;
+                        ent = ((unsigned long long)tag << 32) | ((unsigned long long)px[0] << 16) | ((unsigned long long)px[1] << 8) | px[2];
+                        *slot = ent;
+                    }
+                    return V3<T>((T)(uint32_t)((ent >> 16) & 255u) * color_scale, (T)(uint32_t)((ent >> 8) & 255u) * color_scale, (T)(uint32_t)(ent & 255u) * color_scale);
+                }
+#endif
+                const uint8_t* px = im.rgb + texel * 3;
                 return V3<T>((T)px[0] * color_scale, (T)px[1] * color_scale, (T)px[2] * color_scale);
             }
         }

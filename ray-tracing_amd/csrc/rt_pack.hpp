@@ -522,6 +522,7 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     out.n_perlins = d->n_perlins;
     out.n_perlin_lds = 0;
     out.perlin_lds = nullptr;
+    out.tex_cache = nullptr;
     out.n_world = d->n_world;
     out.n_materials = d->n_materials;
     out.n_lights = d->n_lights;

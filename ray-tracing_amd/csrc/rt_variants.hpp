@@ -17,13 +17,15 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 //    spheres + BVH (random_scene): 4 waves with a 1024-entry head (32 KB + 6 KB tile sums per block) — f64 861 ->
 //    1173 Msamples/s against 2 waves / 2048 entries, f32 1232 -> 1414.  The generic variant (final_scene) stops at
 //    3 waves (f64 122 -> 144; at 4 its 128 registers spill it to half speed).
+//    With the two-way walk over the device's own trees (round 2) a node step is cheaper and the f64 spills weigh more:
+//    f64 3 waves 2026 against 1753 at 4 (and 1664 at 2); f32 stays at 4 (2970 against 2591 at 3).
 //  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
 //    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
-    if (F & F_BVH) return (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) ? 3 : 4;
+    if (F & F_BVH) return ((F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) || sizeof(T) == 8) ? 3 : 4;
     return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
 #endif
 }
