@@ -870,6 +870,9 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
         sure = walk_fast<T, F>(sc, w, o, d, inv, time);
     }
 #endif
+#ifdef RT_DBG_NO_FALLBACK  // (measurement only: what the in-line copy of the exact emulation costs in registers)
+    sure = true;
+#endif
     if (!sure) {
         RT_SIM_COUNT(6);
         walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, false);

@@ -19,13 +19,19 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 //    3 waves (f64 122 -> 144; at 4 its 128 registers spill it to half speed).
 //    With the two-way walk over the device's own trees (round 2) a node step is cheaper and the f64 spills weigh more:
 //    f64 3 waves 2026 against 1753 at 4 (and 1664 at 2); f32 stays at 4 (2970 against 2591 at 3).
+//    The generic f64 variant runs as fast at 2 waves as at 3 (final_scene 1024^2 @ 64 spp: 227 against 225 Msamples/s) with
+//    236 B of spills per lane instead of 576 B: at 3 waves the scratch of all resident waves (113 MB) does not fit the
+//    32 MB of L2 and 257 GB per launch went to HBM (profiles/r02_final_*); at 2 waves it fits.  f32 keeps 3 (370 against 272).
 //  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
 //    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
-    if (F & F_BVH) return ((F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) || sizeof(T) == 8) ? 3 : 4;
+    if (F & F_BVH) {
+        if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? 2 : 3;  // the generic variant (final_scene)
+        return sizeof(T) == 8 ? 3 : 4;                                                      // spheres + BVH (random_scene)
+    }
     return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
 #endif
 }
@@ -33,6 +39,7 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_en
 #ifdef RT_LDS_BVH_ENTRIES
     return RT_LDS_BVH_ENTRIES;
 #else
+    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return 2048u;  // f64 generic: 2 blocks x (64 KB + 6.75 KB Perlin table + 6 KB)
     return (sizeof(T) == 4 && (F & F_NOISE)) ? 1248u : 1024u;  // f32 generic: 3 blocks x (39 KB + 4.75 KB Perlin table + 6 KB)
 #endif
 }
@@ -48,8 +55,11 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin
 #ifndef RT_SORT_TILE_H
 #define RT_SORT_TILE_H 8  // the sorted kernel's tile is 8 pixels wide and this high (rt_kernels.inc)
 #endif
+#ifndef RT_SORT_BLOCK
+#define RT_SORT_BLOCK 256  // lanes per block of the sorted kernel (rt_kernels.inc)
+#endif
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds_bytes() {
-    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * 256u * (uint32_t)sizeof(T) + 6u * 1024u + 192u * RT_SORT_TILE_H + 68u +
+    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * RT_SORT_BLOCK * (uint32_t)sizeof(T) + 24u * RT_SORT_BLOCK + 192u * RT_SORT_TILE_H + 68u +
            lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
 }
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
@@ -59,7 +69,9 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
     constexpr uint32_t most = sizeof(T) == 8 ? 4u : 7u;
 #endif
     // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
-    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (163840u / sorted_lds_bytes<T, F>() >= most ? (int)most : (int)(163840u / sorted_lds_bytes<T, F>()));
+    // blocks per CU that LDS admits x waves per block / 4 SIMDs
+    constexpr uint32_t by_lds = 163840u / sorted_lds_bytes<T, F>() * (RT_SORT_BLOCK / 64u) / 4u;
+    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (by_lds >= most ? (int)most : (int)(by_lds < 1u ? 1u : by_lds));
 }
 }  // namespace rt
 

@@ -6,13 +6,14 @@
 Reads the rocprofv3 CSVs (kernel trace + the separate --pmc passes), averages every counter over the
 dispatches of the dominant kernel, and derives:
   VALU utilisation  = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)   (active lanes per issued VALU instruction)
-  VALU busy         = SQ_ACTIVE_INST_VALU * 4 / (SQ_BUSY_CYCLES-normalised wave slots): reported as the share of
-                      wave-cycles that issued VALU: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles)
+  VALU issue busy   = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): share of all SIMD issue cycles that issued VALU
+  VALU lane-slots   = issue busy x utilisation: share of all lane-slots (1024 SIMDs x 16 lanes x cycles) that executed
+  (also: the share of wave-cycles that issued VALU, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, both in quad-cycles)
   HBM bytes/launch  = 2 * FETCH_SIZE KiB (gfx950 correction for wide reads, MI355X_MICROARCH.md §HBM — an UPPER
                       bound for this kernel's narrow reads) + WRITE_SIZE KiB
   L2 hit rate       = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
 Writes <out>_summary.md, <out>_summary.json, copies the kernel-stats CSV, and updates profiles/hbm_traffic.json
-(the `traffic` field of bench.py's roofline)."""
+(superseded) / profiles/pmc_views.json (the `traffic` and `executed` fields of bench.py's roofline)."""
 import csv
 import glob
 import json
@@ -54,6 +55,11 @@ def main():
                         ("SQ_WAIT_INST_ANY", "wait_inst_share_pct")):
             if g(k) is not None:
                 d[name] = 100.0 * g(k) / g("SQ_WAVE_CYCLES")
+    if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+        # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        d["valu_issue_busy_pct"] = 100.0 * 4.0 * g("SQ_ACTIVE_INST_VALU") / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
+        if "valu_utilization_pct" in d:
+            d["valu_lane_slot_pct"] = d["valu_issue_busy_pct"] * d["valu_utilization_pct"] / 100.0
     if g("SQ_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
         d["mean_waves_in_flight_per_se"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES")
     if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
@@ -76,7 +82,7 @@ def main():
                     f"(min {float(kstat['MinNs'])/1e6:.3f}, max {float(kstat['MaxNs'])/1e6:.3f}), {kstat['Percentage']} % of GPU time\n\n")
         if meta:
             f.write("dispatch: grid {Grid_Size}, workgroup {Workgroup_Size}, VGPR {VGPR_Count} + AGPR {Accum_VGPR_Count}, SGPR {SGPR_Count}, "
-                    "LDS {LDS_Block_Size} B, scratch {Scratch_Size} B/lane\n\n".format(**meta))
+                    "LDS {LDS_Block_Size} B, scratch {Scratch_Size} B/lane  (register counts as rocprofv3 reports them: per-lane allocation in its own granule units, see tools/kernel_resources.sh for the compiler's counts)\n\n".format(**meta))
         f.write("| derived | value |\n|---|---|\n")
         for k, v in d.items():
             f.write(f"| {k} | {v:,.3f} |\n")
@@ -84,10 +90,19 @@ def main():
         for k in sorted(avg):
             f.write(f"| {k} | {avg[k]:,.0f} |\n")
     print(open(out + "_summary.md").read())
-    if "hbm_bytes_per_launch" in d and len(sys.argv) > 4:
-        p = os.path.join(os.path.dirname(out) or ".", "hbm_traffic.json")
+    if len(sys.argv) > 4:  # key "<scene>_<W>x<H>_<spp>spp_<precision>": the hardware view bench.py prints as roofline.executed / .traffic
+        p = os.path.join(os.path.dirname(out) or ".", "pmc_views.json")
         rec = json.load(open(p)) if os.path.exists(p) else {}
-        rec[sys.argv[4]] = {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "from": os.path.basename(out)}
+        view = {"from": os.path.basename(out)}
+        if "hbm_bytes_per_launch" in d:
+            view["hbm_bytes_per_launch"] = d["hbm_bytes_per_launch"]
+        if "valu_utilization_pct" in d:
+            view["valu_lanes_active_frac"] = round(d["valu_utilization_pct"] / 100.0, 4)
+        if "valu_issue_busy_pct" in d:
+            view["valu_issue_busy_frac"] = round(d["valu_issue_busy_pct"] / 100.0, 4)
+        if "valu_lane_slot_pct" in d:
+            view["valu_lane_slot_frac"] = round(d["valu_lane_slot_pct"] / 100.0, 4)
+        rec[sys.argv[4]] = view
         json.dump(rec, open(p, "w"), indent=1)
 
 
