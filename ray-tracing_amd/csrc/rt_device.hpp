@@ -384,11 +384,18 @@ template <class T> __device__ inline Ray<T> get_ray(const DCamera<T>& c, T s, T 
 // Select form: the in-plane point is computed for every lane; the comparisons are the reference's.
 // The reciprocals of a ray's direction components, shared by every rectangle test of that ray in one space
 // (world, or an instance's object space): see Recip.
+#if defined(RT_SHARED_RECIP)
 template <class T> struct RayInv {
     Recip<T> x, y, z;
     __device__ explicit RayInv(V3<T> d) : x(d.x), y(d.y), z(d.z) {}
-    __device__ const Recip<T>& on(int axis) const { return axis == 0 ? z : (axis == 1 ? y : x); }  // XY -> z, XZ -> y, YZ -> x
+    __device__ Recip<T> on(int axis, V3<T>) const { return axis == 0 ? z : (axis == 1 ? y : x); }  // XY -> z, XZ -> y, YZ -> x
 };
+#else
+template <class T> struct RayInv {  // plain divisions: nothing to carry, the divider is made from the direction at the test
+    __device__ explicit RayInv(V3<T>) {}
+    __device__ PlainDiv<T> on(int axis, V3<T> d) const { return PlainDiv<T>(axis == 0 ? d.z : (axis == 1 ? d.y : d.x)); }
+};
+#endif
 template <class T, class Div>
 __device__ inline bool rect_hit(int axis, T a1, T a2, T b1, T b2, T k, V3<T> o, V3<T> d, const Div& inv_dk, T t_min, T t_max, T& t_out) {
     const T ok = axis == 0 ? o.z : (axis == 1 ? o.y : o.x);
@@ -426,6 +433,11 @@ __device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_
     }
     return false;
 }
+template <class T>
+__device__ inline bool sphere_hit(V3<T> center, T radius, V3<T> o, V3<T> d, T t_min, T t_max, T& t_out) {
+    bool tie = false;
+    return sphere_hit(center, radius, o, d, t_min, t_max, t_out, tie);
+}
 // src/objects.rs:154-158
 template <class T> __device__ inline V3<T> moving_center(const DPrim<T>& p, T time) {
     V3<T> c1(p.d), c2(p.d + 3);
@@ -444,24 +456,20 @@ template <class T> __device__ inline void cuboid_side(const DPrim<T>& p, int i, 
 
 // Closest hit of ONE primitive in (t_min, t_max); side = cuboid face.
 template <class T, uint32_t F>
-__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side, bool& tie) {
+__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side) {
     side = 0;
-    tie = false;
     const uint32_t kind = p.kind;
     if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && kind <= 1) {  // one sphere test for both kinds: mixed leaves stay converged
         V3<T> center(p.d);
         T radius = p.d[3];
         if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
-        return sphere_hit(center, radius, o, d, t_min, t_max, t_out, tie);
+        return sphere_hit(center, radius, o, d, t_min, t_max, t_out);
     }
     if (has<F>(F_RECT) && kind >= 2 && kind <= 4) {
         // one copy per axis behind a wave-uniform branch: with a run-time axis the six component picks are 12 selects
-        bool h;
-        if (kind == 2) h = rect_hit<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.z, t_min, t_max, t_out);
-        else if (kind == 3) h = rect_hit<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.y, t_min, t_max, t_out);
-        else h = rect_hit<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.x, t_min, t_max, t_out);
-        tie = h & (t_out == t_max);
-        return h;
+        if (kind == 2) return rect_hit<T>(0, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.on(0, d), t_min, t_max, t_out);
+        if (kind == 3) return rect_hit<T>(1, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.on(1, d), t_min, t_max, t_out);
+        return rect_hit<T>(2, p.d[0], p.d[1], p.d[2], p.d[3], p.d[4], o, d, inv.on(2, d), t_min, t_max, t_out);
     }
     if (has<F>(F_CUBOID) && kind == 5) {  // six sides in tuple order, shrinking closest (src/objects.rs:458-485)
         bool any = false;
@@ -471,19 +479,31 @@ __device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayIn
             int axis; T a1, a2, b1, b2, k, face;
             cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
             T t = closest;
-            const bool h = rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, inv.on(axis), t_min, closest, t);
+            const bool h = rect_hit<T>(axis, a1, a2, b1, b2, k, o, d, inv.on(axis, d), t_min, closest, t);
             any |= h; closest = t; side = h ? i : side;
         }
         t_out = closest;
-        tie = any & (closest == t_max);
         return any;
     }
     return false;
 }
+// The same test for walk_fast, which also needs to know about equal distances (`tie`, see rect_hit's note).  Kept as a
+// separate function: folding the flag into prim_hit changed the code generated for the kernels that never use it
+// (cornell_box -1.5 %).
 template <class T, uint32_t F>
-__device__ inline bool prim_hit(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side) {
-    bool tie;
-    return prim_hit<T, F>(p, o, d, inv, time, t_min, t_max, t_out, side, tie);
+__device__ inline bool prim_hit_tie(const DPrim<T>& p, V3<T> o, V3<T> d, const RayInv<T>& inv, T time, T t_min, T t_max, T& t_out, int& side, bool& tie) {
+    tie = false;
+    const uint32_t kind = p.kind;
+    if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && kind <= 1) {
+        side = 0;
+        V3<T> center(p.d);
+        T radius = p.d[3];
+        if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
+        return sphere_hit(center, radius, o, d, t_min, t_max, t_out, tie);
+    }
+    const bool h = prim_hit<T, F>(p, o, d, inv, time, t_min, t_max, t_out, side);
+    tie = h & (t_out == t_max);  // inclusive tests: a hit AT t_max is accepted
+    return h;
 }
 
 // src/bvh.rs:26-58 — loose slab test, true divisions, minNum/maxNum; all three axes evaluated
@@ -832,7 +852,7 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
         T t; int side; bool tie;
         const bool any_before = w.any;
         RT_SIM_COUNT(2);
-        if (prim_hit<T, F>(sc.prims[prim], o, d, inv, time, w.t_min, closest, t, side, tie)) {
+        if (prim_hit_tie<T, F>(sc.prims[prim], o, d, inv, time, w.t_min, closest, t, side, tie)) {
             RT_SIM_COUNT(3);
             w.any = true; closest = t; w.prim = prim; w.side = side;
             ref_parent = e.skip;  // a leaf's skip field: its parent node's entry in the reference's tree
@@ -960,15 +980,20 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             if (nan) return false;  // (chk is also NaN for inf - inf: those rays take the normal route)
         }
     }
-    // rectangle tests divide by a direction component: the reciprocal part of those divisions is shared per axis (Recip)
-    constexpr bool kRects = has<F>(F_RECT) || has<F>(F_CUBOID);
-    const RayInv<T> inv_world(kRects ? ray.dir : V3<T>(T(1), T(1), T(1)));
     for (uint32_t i = 0; i < sc.n_world; i++) {
         const DInstance<T>& in = sc.world[i];
         V3<T> o = ray.ori, d = ray.dir;
+#if defined(RT_SHARED_RECIP)
+        // rectangle tests divide by a direction component: the reciprocal part of those divisions is shared per axis and,
+        // where no RotateY intervenes, per ray (Recip)
+        constexpr bool kRects = has<F>(F_RECT) || has<F>(F_CUBOID);
         const bool rotated = xform_ray<T, F>(sc, in, o, d);
-        RayInv<T> inv = inv_world;
+        RayInv<T> inv(kRects ? ray.dir : V3<T>(T(1), T(1), T(1)));
         if (kRects && rotated) { inv.x = Recip<T>(d.x); inv.z = Recip<T>(d.z); }  // RotateY keeps d.y (wave-uniform branch)
+#else
+        xform_ray<T, F>(sc, in, o, d);
+        const RayInv<T> inv(d);  // plain divisions: just the direction
+#endif
         const bool med = has<F>(F_MEDIUM) && in.is_medium;
         T ta = T(0);
         const int passes = med ? 2 : 1;

@@ -88,3 +88,54 @@ def random_scene(seed, with_bvh=True, with_media=True, with_lights=True):
             fs.add_light(cb)
     fs.camera([U(8, 14), U(1, 5), U(8, 14)], [0, 0.5, 0], [0, 1, 0], U(25, 50), 1.0, rng.choice([0.0, 0.2]), 12.0, 0.0, 1.0)
     return fs
+
+
+def tie_scene(seed):
+    """Scenes built to hit what the device's own tree order could get wrong (rt_device.hpp: walk_fast): EQUAL hit distances
+    inside one BVH (the same sphere / cuboid / rectangle twice with different materials: spheres keep the first in the
+    reference's order, rectangles and cuboids take the last), a grid of cuboids with shared faces as in final_scene's ground,
+    spheres tangent to their neighbours' boxes, integer coordinates and an axis-aligned camera on a grid line, so that
+    many rays run exactly in a coordinate plane (a zero direction component: 0/0 and x/0 in the slab tests) or hit
+    exactly on box faces and edges."""
+    rng = random.Random(1000 + seed)
+    fs = F.FlatScene()
+    fs.background = [0.7, 0.8, 1.0]
+
+    def m(i):
+        return fs.material(F.LAMBERTIAN, texture=fs.solid(0.1 + 0.07 * (i % 12), 0.9 - 0.05 * (i % 15), 0.3 + 0.04 * (i % 9)))
+
+    ids = []
+    k = 0
+    # ground grid of cuboids with shared side faces and a few equal heights (shared top edges)
+    n = rng.randrange(3, 6)
+    for ix in range(n):
+        for iz in range(n):
+            h = float(rng.choice([1, 1, 2, 3]))
+            ids.append(fs.cuboid([2.0 * ix - n, -1.0, 2.0 * iz - n], [2.0 * ix - n + 2.0, h, 2.0 * iz - n + 2.0], m(k))); k += 1
+    # the same primitives twice (other material), appended in random places of the build order
+    dup = []
+    for _ in range(rng.randrange(2, 5)):
+        c = [float(rng.randrange(-n, n)), float(rng.randrange(4, 7)), float(rng.randrange(-n, n))]
+        r = float(rng.choice([1, 1, 2]))
+        dup += [fs.sphere(c, r, m(k)), fs.sphere(c, r, m(k + 1))]; k += 2
+    for _ in range(rng.randrange(1, 3)):
+        lo = [float(rng.randrange(-n, n)), 4.0, float(rng.randrange(-n, n))]
+        hi = [lo[0] + 1.0, 5.0, lo[2] + 2.0]
+        dup += [fs.cuboid(lo, hi, m(k)), fs.cuboid(lo, hi, m(k + 1))]; k += 2
+    a1 = float(rng.randrange(-n, 0))
+    dup += [fs.rect(1, a1, a1 + 3.0, -2.0, 2.0, 7.0, -1.0, m(k)), fs.rect(1, a1, a1 + 3.0, -2.0, 2.0, 7.0, 1.0, m(k + 1))]; k += 2
+    # spheres resting on the grid (tangent to the cuboid tops) and touching each other
+    for _ in range(rng.randrange(2, 5)):
+        ix, iz = rng.randrange(n), rng.randrange(n)
+        dup.append(fs.sphere([2.0 * ix - n + 1.0, 4.0, 2.0 * iz - n + 1.0], 1.0, m(k))); k += 1
+    ids += dup
+    rng.shuffle(ids)
+    chain = () if seed % 3 else (("t", (1.0, 0.0, -2.0)),)
+    fs.add_world(fs.build_bvh(ids, rng), bvh=True, chain=chain)
+    # something in front of and something behind the tree in the world list, one of them at a distance equal to a tree hit
+    fs.add_world(fs.rect(1, -30, 30, -30, 30, -1.0, 1.0, m(k)))  # the plane of the cuboids' bottoms
+    if seed % 2:
+        fs.add_world(fs.sphere([0.0, 4.0, 0.0], 1.0, m(k + 1)))
+    # on a grid line, looking along -z: the centre column of an odd-width probe has d.x == 0 exactly
+    fs.camera([0.0, 5.0, 3.0 * n + 6.0], [0.0, 2.0, 0.0] if seed % 2 else [0.0, 5.0, 0.0], [0, 1, 0], 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return fs

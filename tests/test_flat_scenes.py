@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import random_scene
+from flat_fuzz import random_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -49,6 +49,25 @@ def test_random_flat_scene_sim_equals_oracle(sim, seed):
     ref, cnt = oc.render(20, 15, 0, 4, threads=4)
     assert casts == cnt["casts"], (seed, casts, cnt["casts"])
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True), (seed, np.nanmax(np.abs(got - ref)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tie_scene_sim_equals_oracle(sim, seed):
+    # equal hit distances, shared faces, rays in coordinate planes: where the device's own tree order (walk_fast) must hand over to
+    # the reference-order walk.  ids and t bit-exact on an odd-width probe (centre column: d.x == 0) and an even one.
+    host = rt.FlatHostScene(tie_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    for (W, H) in ((41, 31), (48, 36)):
+        for generic in (False, True):
+            ids, ts = sc.primary(W, H, 0.25, 0.5, "f64", generic)
+            oi, ot = oc.trace_primary(W, H, 0.25, 0.5)
+            assert np.array_equal(ids, oi), (seed, W, generic, int((ids != oi).sum()))
+            assert np.array_equal(ts, ot)
+    got, casts = sc.render(21, 15, 0, 3)
+    ref, cnt = oc.render(21, 15, 0, 3, threads=4)
+    assert casts == cnt["casts"], (seed, casts, cnt["casts"])
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
 
 
 def test_flat_scene_dict_roundtrip():

@@ -236,3 +236,27 @@ def test_json_scene_boxes_on_the_device_path(gpu, golden_dir):
         ids, ts = ds.trace_primary(64, 64, 0.0, 0.5, "f64")
         assert np.array_equal(ids.cpu().numpy(), fx["ids"]) and np.array_equal(ts.cpu().numpy(), fx["t"])
         ds.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tie_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: tie_scene — equal hit distances inside one BVH, shared cuboid faces, rays in coordinate planes: the cases
+    # where the walk over the device's own tree must fall back to the reference-order walk (rt_device.hpp: walk_fast)
+    from flat_fuzz import tie_scene
+    host = rt.FlatHostScene(tie_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        for (W, H) in ((41, 31), (96, 72)):
+            ids, ts = ds.trace_primary(W, H, 0.25, 0.5, "f64")
+            oi, ot = oc.trace_primary(W, H, 0.25, 0.5)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot)
+        W, H, spp = 40, 30, 4
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
