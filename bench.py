@@ -228,6 +228,7 @@ def main():
     if a.dry_run:
         return dry_run(a, in_rank)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC; must be in the environment before the first HIP call
     import torch
     import torch.distributed as dist
 
@@ -244,7 +245,6 @@ def main():
     dev = torch.device(f"cuda:{local}")
     use_dist = in_rank  # under torchrun the exchange step runs even at N = 1 (a 1-rank RCCL all-reduce)
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; plumbing: barrier, max of the clocks, id broadcast
 
     desc = rt.init(local)
