@@ -273,6 +273,9 @@ int rt_debug_sample_pixel(RtScene* scene, const RtRenderParams* params, uint32_t
  * (rt_device.hpp: Recip) that must equal IEEE division bit for bit; d_shared[i] = n[i]/d[i] by that routine,
  * d_plain[i] by the compiler's `/`. */
 int rt_debug_divide(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, void* stream);
+/* Test hook, no counterpart in the reference: the UNGUARDED shared-denominator quotient routine that unit(v) and v / s use
+ * on the device (rt_device.hpp: RecipCore); d_flag[i] = 1 where |d[i]| lies outside [2^-400, 2^400). */
+int rt_debug_divide_fast(const double* d_n, const double* d_d, uint64_t count, double* d_out, uint32_t* d_flag, void* stream);
 
 /* Small helpers so a host without another HIP binding can drive the library. */
 int rt_device_alloc(void** d_ptr, uint64_t bytes);

@@ -335,6 +335,16 @@ int rt_debug_divide(const double* d_n, const double* d_d, uint64_t count, double
     return RT_OK;
 }
 
+/* Test hook: d_out[i] = n[i] / d[i] by the unguarded shared-denominator routine (rt_device.hpp: RecipCore), d_flag[i] = 1 where
+ * the denominator lies outside the range for which the routine is IEEE division. */
+int rt_debug_divide_fast(const double* d_n, const double* d_d, uint64_t count, double* d_out, uint32_t* d_flag, void* stream) {
+    if (!d_n || !d_d || !d_out || !d_flag) return fail(RT_ERR_INVALID, "NULL buffer");
+    if (count == 0) return RT_OK;
+    if (count > 0xffffffffull * 256ull) return fail(RT_ERR_INVALID, "count too large");
+    HIP_TRY(rt::launch_divide_fast(d_n, d_d, count, d_out, d_flag, (hipStream_t)stream));
+    return RT_OK;
+}
+
 int rt_resolve(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb, void* stream) {
     if (!d_accum || !d_rgb) return fail(RT_ERR_INVALID, "NULL buffer");
     if (width == 0 || height == 0 || spp == 0 || (uint64_t)width * height * 3 > 0xffffffffull) return fail(RT_ERR_INVALID, "bad width/height/spp");

@@ -13,6 +13,20 @@ __global__ void divide_check_kernel(const double* __restrict__ n, const double* 
     shared[i] = r.div(n[i]);
     plain[i] = n[i] / d[i];
 }
+// (rt_debug_divide_fast): the unguarded quotient routine (RecipCore: what unit(v) and v / s use)
+__global__ void divide_fast_kernel(const double* __restrict__ n, const double* __restrict__ d, uint64_t count, double* __restrict__ out, uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+#ifdef RT_HAVE_RECIP_CORE  // (device pass only: the routine is built from device builtins)
+    const RecipCore f(d[i]);
+    out[i] = f.quot(n[i]);
+    flag[i] = RecipCore::moderate(d[i]) ? 0u : 1u;
+#endif
+}
+hipError_t launch_divide_fast(const double* d_n, const double* d_d, uint64_t count, double* d_out, uint32_t* d_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(divide_fast_kernel, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, d_n, d_d, count, d_out, d_flag);
+    return hipGetLastError();
+}
 hipError_t launch_divide_check(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, hipStream_t stream) {
     hipLaunchKernelGGL(divide_check_kernel, dim3((uint32_t)((count + 255u) / 256u)), dim3(256), 0, stream, d_n, d_d, count, d_shared, d_plain);
     return hipGetLastError();

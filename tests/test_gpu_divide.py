@@ -65,3 +65,63 @@ def test_shared_reciprocal_division_is_ieee_division(gpu):
             ok = same_bits(shared, want)
             # the device flushes nothing and rounds correctly; the only tolerated difference is none
             assert ok.all(), (n[~ok][:4], d[~ok][:4], shared[~ok][:4], want[~ok][:4])
+
+
+def run_fast(n, d):
+    n = torch.from_numpy(np.ascontiguousarray(n, dtype=np.float64)).cuda()
+    d = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float64)).cuda()
+    out = torch.empty_like(n)
+    flag = torch.empty(n.numel(), dtype=torch.int32, device="cuda")
+    rc = _ffi.hip().rt_debug_divide_fast(C.c_void_p(n.data_ptr()), C.c_void_p(d.data_ptr()), n.numel(), C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(flag.data_ptr()), None)
+    assert rc == 0, _ffi.hip().rt_last_error()
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), flag.cpu().numpy().astype(bool)
+
+
+def test_unguarded_shared_denominator_quotient(gpu):
+    """RecipCore's contract (rt_device.hpp; what unit(v) and v / s run on the device): with the denominator in
+    [2^-400, 2^400) — the flag marks everything else — the quotient is IEEE division bit for bit for numerators of magnitude
+    [2^-600, 2^600] and for 0 (and, through div_fixup, for inf / NaN); smaller numerators give a quotient below 2^-190 in
+    magnitude like the true one."""
+    rs = np.random.RandomState(11)
+    N = 1 << 22
+    cases = []
+    cases.append((rs.uniform(-1000, 1000, N), rs.uniform(-2, 2, N)))
+    cases.append((rs.randint(0, 2 ** 63, N, dtype=np.int64).view(np.float64) * rs.choice([-1.0, 1.0], N),
+                  rs.randint(0, 2 ** 63, N, dtype=np.int64).view(np.float64) * rs.choice([-1.0, 1.0], N)))
+    m = np.array([0x0, 0x1, 0xFFFFFFFFFFFFF, 0xFFFFFFFFFFFFE, 0x8000000000000, 0x7FFFFFFFFFFFF, 0x5555555555555, 0xAAAAAAAAAAAAA], dtype=np.uint64)
+    en = np.arange(1023 - 620, 1023 + 621, 3, dtype=np.uint64)
+    ed = np.arange(1023 - 405, 1023 + 406, 2, dtype=np.uint64)
+    gn = ((en[:, None] << np.uint64(52)) | m[None, :]).reshape(-1).view(np.float64)
+    gd = ((ed[:, None] << np.uint64(52)) | m[None, :]).reshape(-1).view(np.float64)
+    a, b = np.meshgrid(gn, gd)
+    cases.append((a.reshape(-1), b.reshape(-1)))
+    cases.append((-a.reshape(-1), b.reshape(-1)))
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1.0, -3.0, 1e-300, 1e300,
+                   2.0 ** -400, 2.0 ** 400, np.nextafter(2.0 ** -400, 0), np.nextafter(2.0 ** 400, 0), 2.0 ** -600, 2.0 ** 600])
+    sn, sd = np.meshgrid(sp, sp)
+    cases.append((sn.reshape(-1), sd.reshape(-1)))
+    o = rs.uniform(-800, 800, N); k = rs.choice([0.0, 555.0, 554.0, 165.0, 330.0], N); dd = rs.standard_normal(N) * rs.choice([1.0, 1e-3, 1e-9, 400.0], N)
+    cases.append((k - o, dd))
+    cases.append((np.where(rs.uniform(size=N) < 0.3, 0.0, (k - o) * 1e-13), dd))  # zero and rounding-size numerators
+    v = rs.standard_normal((N, 3)) * rs.choice([1.0, 1e-6, 555.0], N)[:, None]; v[rs.uniform(size=N) < 0.2, 1] = 0.0  # unit(v): components over the length
+    ln = np.sqrt((v * v).sum(1))
+    for c in range(3):
+        cases.append((v[:, c], ln))
+    checked = 0
+    with np.errstate(all="ignore"):
+        for n, d in cases:
+            got, flag = run_fast(n, d)
+            ad = np.abs(d)
+            moderate = (ad >= 2.0 ** -400) & (ad < 2.0 ** 400)
+            assert (flag == ~moderate).all(), "the denominator check must flag exactly the denominators outside [2^-400, 2^400)"
+            want = n / d
+            an = np.abs(n)
+            exact = moderate & (((an >= 2.0 ** -600) & (an <= 2.0 ** 600)) | (n == 0) | ~np.isfinite(n))
+            ok = same_bits(got, want)
+            assert ok[exact].all(), (n[exact & ~ok][:4], d[exact & ~ok][:4], got[exact & ~ok][:4], want[exact & ~ok][:4])
+            tiny = moderate & (an < 2.0 ** -600) & (n != 0)
+            assert (np.abs(got[tiny]) < 2.0 ** -190).all() and (np.abs(want[tiny]) < 2.0 ** -190).all()
+            checked += int(exact.sum())
+    assert checked > 8_000_000
