@@ -255,6 +255,7 @@ def main():
     stats = torch.zeros(4, dtype=torch.int64, device=dev)
 
     exchange = None
+    exchange_note = None
     comm = None
     if use_dist:
         exchange = a.exchange
@@ -265,7 +266,37 @@ def main():
                     t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
                 dist.broadcast(t, 0)
                 return bytes(t.cpu().numpy().tobytes())
-            comm = rt.Comm(rank, world, bcast, local)
+
+            def all_agree(ok):  # every rank takes the same route, or the collectives below would hang
+                f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                return bool(f.item())
+
+            # 1. can every rank bind RCCL through the library (dlopen)?  (an id made here is simply dropped)
+            why = ""
+            try:
+                rt.comm_probe()
+                ok = True
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"{type(e).__name__}: {e}"
+            if all_agree(ok):
+                # 2. the communicator (collective), then one known all-reduce through it
+                try:
+                    comm = rt.Comm(rank, world, bcast, local)
+                    probe = torch.ones(1024, dtype=torch.float32, device=dev)
+                    comm.all_reduce(probe)
+                    torch.cuda.synchronize(dev)
+                    ok = bool((probe == float(world)).all().item())
+                    why = "" if ok else "probe all-reduce gave a wrong sum"
+                except Exception as e:  # noqa: BLE001
+                    ok, why = False, f"{type(e).__name__}: {e}"
+                ok = all_agree(ok)
+            if not ok:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                exchange = "torch"
+                exchange_note = "rt exchange unavailable on some rank, torch.distributed used" + (f" (this rank: {why})" if why else "")
 
     def all_reduce(buf):
         if comm is not None:
@@ -409,6 +440,8 @@ def main():
             "image_mean": round(image_mean, 6),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if exchange_note:
+            line["exchange_note"] = exchange_note
         if ar_ms:
             line["allreduce_ms"] = round(sum(ar_ms) / len(ar_ms), 4)
             line["allreduce_bytes"] = W * H * 12

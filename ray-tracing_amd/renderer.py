@@ -174,6 +174,13 @@ def resolve(accum, spp):
     return rgb
 
 
+def comm_probe():
+    """Raises unless this process can bind RCCL through the library (rt_exchange.hip loads it at first use).  The id the
+    call makes is dropped: an id only becomes a communicator in rt_comm_create."""
+    buf = (C.c_uint8 * _ffi.RT_COMM_ID_BYTES)()
+    check(_ffi.hip().rt_comm_unique_id(buf))
+
+
 class Comm:
     """The exchange step through the C-ABI (rt_comm_* / rt_allreduce_*: one RCCL all-reduce of the accumulation
     buffers).  `broadcast_bytes(b: bytes or None) -> bytes` ships rank 0's 128-byte id to every rank (any
