@@ -168,7 +168,7 @@ typedef struct RtSceneDesc {
     uint32_t n_perlins;   const RtPerlin* perlins;
     uint32_t n_images;    const RtImage* images;
     uint32_t n_xforms;    const RtXform* xforms;
-    uint32_t n_world;     const RtInstance* world;  /* ObjectList order is semantically relevant */
+    uint32_t n_world;     const RtInstance* world;  /* ObjectList order is semantically relevant; 0 objects is a valid (all-background) world */
     uint32_t n_lights;    const RtInstance* lights; /* 0 <=> lights = None */
     RtBvh bvh;
     double background[3];

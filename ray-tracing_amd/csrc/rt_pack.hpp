@@ -89,9 +89,9 @@ inline int validate_light_ranges(const RtSceneDesc* d);
 inline int validate(const RtSceneDesc* d) {
     if (!d) return fail(RT_ERR_INVALID, "scene description is NULL");
     if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID, "abi_version mismatch");
-    if (d->n_world == 0) return fail(RT_ERR_INVALID, "world is empty");
+    // (an empty world is a valid ObjectList, src/objects.rs:38-48: every ray returns the background)
     if ((d->n_prims && !d->prims) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures) ||
-        (d->n_perlins && !d->perlins) || (d->n_images && !d->images) || (d->n_xforms && !d->xforms) || !d->world ||
+        (d->n_perlins && !d->perlins) || (d->n_images && !d->images) || (d->n_xforms && !d->xforms) || (d->n_world && !d->world) ||
         (d->n_lights && !d->lights))
         return fail(RT_ERR_INVALID, "NULL array with non-zero count");
     for (uint32_t i = 0; i < d->n_textures; i++) {

@@ -70,6 +70,28 @@ def test_tie_scene_sim_equals_oracle(sim, seed):
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
 
 
+def empty_world_scene():
+    fs = flat.FlatScene()
+    fs.background = [0.25, 0.5, 0.75]
+    fs.camera((0.0, 1.0, -5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 4.0 / 3.0, 0.1, 5.0)
+    return fs
+
+
+def test_empty_world_is_all_background(sim):
+    # an ObjectList without objects is valid in the reference (objects.rs:38-48: hit -> None): every sample is the background
+    host = rt.FlatHostScene(empty_world_scene())
+    assert host.desc.n_world == 0
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    ids, ts = sc.primary(12, 9, 0.0, 0.5, "f64")
+    oi, ot = oc.trace_primary(12, 9, 0.0, 0.5)
+    assert (ids == -1).all() and np.array_equal(ids, oi) and np.array_equal(ts, ot)
+    got, casts = sc.render(12, 9, 0, 4)
+    ref, cnt = oc.render(12, 9, 0, 4, threads=2)
+    assert casts == cnt["casts"] == 12 * 9 * 4
+    assert np.array_equal(got, ref) and np.allclose(got / 4, [0.25, 0.5, 0.75])
+
+
 def test_flat_scene_dict_roundtrip():
     fs = random_scene(3)
     fs2 = flat.FlatScene.from_dict(json.loads(json.dumps(fs.to_dict())))

@@ -260,3 +260,25 @@ def test_tie_scene_gpu_equals_oracle(seed, gpu):
         assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("precision", ("f64", "f32"))
+def test_empty_world_on_the_device(precision, gpu):
+    # an ObjectList without objects (src/objects.rs:38-48): no hit anywhere, every sample is the background; ragged frame
+    from test_flat_scenes import empty_world_scene
+    host = rt.FlatHostScene(empty_world_scene())
+    ds = rt.DeviceScene(host, 0)
+    try:
+        ids, ts = ds.trace_primary(13, 9, 0.0, 0.5, precision)
+        assert (ids.cpu().numpy() == -1).all()
+        for no_sort in (False, True):
+            acc = torch.zeros((9, 13, 3), dtype=torch.float32, device="cuda:0")
+            st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            ds.render_into(acc, 0, 5, precision=precision, stats=st, no_sort=no_sort)
+            assert st.cpu().tolist() == [13 * 9 * 5, 13 * 9 * 5, 0, 0]
+            assert np.allclose(acc.cpu().numpy() / 5, [0.25, 0.5, 0.75], rtol=1e-6)
+        rgb = ds.render_rgb8(13, 9, 0, 5, precision=precision).cpu().numpy()
+        want = (np.clip(np.sqrt(np.array([0.25, 0.5, 0.75])), 0, 0.99999) * 256).astype(np.uint8)
+        assert (rgb == want).all()
+    finally:
+        ds.close()
