@@ -40,17 +40,23 @@ void orc_trace_primary(void* s, uint32_t W, uint32_t H, double time, double medi
 }
 
 // counters_out[16]: paths, casts, prim_tests, node_visits, nan_retries, misses, depth_exhausted,
-// flops, scatters[0..5] (lambertian, metal, dielectric, light, isotropic, frosted), unit_zero
-void orc_render(void* s, uint32_t W, uint32_t H, uint32_t s0, uint32_t n, int depth, uint64_t seed, int threads,
-                double* accum, double* counters_out) {
-    Counters c = render(*(Scene*)s, W, H, s0, n, depth, seed, threads, accum);
+// flops, scatters[0..5] (lambertian, metal, dielectric, light, isotropic, frosted), dropped, 0
+// max_retries: a sample whose radiance is NaN is retried (ray_tracing.rs:102-110) at most this many times, then
+// counted as dropped and taken as zero (the reference retries for ever; the device build caps at 64 by default)
+void orc_render_ex(void* s, uint32_t W, uint32_t H, uint32_t s0, uint32_t n, int depth, uint64_t seed, int threads, int max_retries,
+                   double* accum, double* counters_out) {
+    Counters c = render(*(Scene*)s, W, H, s0, n, depth, seed, threads, accum, max_retries);
     if (counters_out) {
         counters_out[0] = (double)c.paths; counters_out[1] = (double)c.casts; counters_out[2] = (double)c.prim_tests;
         counters_out[3] = (double)c.node_visits; counters_out[4] = (double)c.nan_retries; counters_out[5] = (double)c.misses;
         counters_out[6] = (double)c.depth_exhausted; counters_out[7] = c.flops;
         for (int i = 0; i < 6; i++) counters_out[8 + i] = (double)c.scatters[i];
-        counters_out[14] = 0; counters_out[15] = 0;
+        counters_out[14] = (double)c.dropped; counters_out[15] = 0;
     }
+}
+void orc_render(void* s, uint32_t W, uint32_t H, uint32_t s0, uint32_t n, int depth, uint64_t seed, int threads,
+                double* accum, double* counters_out) {
+    orc_render_ex(s, W, H, s0, n, depth, seed, threads, 64, accum, counters_out);
 }
 
 // One sample's radiance (for sample-for-sample comparison with the f64 device instantiation).

@@ -22,12 +22,13 @@ struct Counters {
     unsigned long long paths = 0, casts = 0, prim_tests = 0, node_visits = 0, nan_retries = 0;
     unsigned long long scatters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long misses = 0, depth_exhausted = 0;
+    unsigned long long dropped = 0;  // samples given up after max_retries NaN results (the cap is this build's, not the reference's)
     double flops = 0;  // algorithmic flops by the conventions of SURVEY.md 8(d)
     void add(const Counters& o) {
         paths += o.paths; casts += o.casts; prim_tests += o.prim_tests;
         node_visits += o.node_visits; nan_retries += o.nan_retries;
         for (int i = 0; i < 8; i++) scatters[i] += o.scatters[i];
-        misses += o.misses; depth_exhausted += o.depth_exhausted; flops += o.flops;
+        misses += o.misses; depth_exhausted += o.depth_exhausted; dropped += o.dropped; flops += o.flops;
     }
 };
 extern thread_local Counters g_cnt;

@@ -116,14 +116,14 @@ inline Vec3 sample_pixel(const Scene& sc, uint32_t W, uint32_t H, uint32_t x, ui
         Vec3 rec = ray_color(ray, *sc.world, sc.background, sc.lights.get(), max_depth, rng);
         if (!(rec.x != rec.x || rec.y != rec.y || rec.z != rec.z)) return rec;
         ORC_CNT(g_cnt.nan_retries++);
-        if (attempt >= max_retries) return Vec3::zero();  // device caps retries the same way
+        if (attempt >= max_retries) { ORC_CNT(g_cnt.dropped++); return Vec3::zero(); }  // device caps retries the same way
     }
 }
 
 // Render: accum[(y*W+x)*3+c] += sum over samples [s0, s0+n) of the accepted radiance (linear,
 // un-normalised, f64).  Jobs are x-strips, n_jobs = threads*16, as ray_tracing.rs:83-88.
 inline Counters render(const Scene& sc, uint32_t W, uint32_t H, uint32_t s0, uint32_t n, int max_depth,
-                       uint64_t seed, int threads, double* accum) {
+                       uint64_t seed, int threads, double* accum, int max_retries = 64) {
     if (threads < 1) threads = 1;
     uint32_t n_jobs = (uint32_t)threads * 16;
     std::atomic<uint32_t> next_job(0);
@@ -139,7 +139,7 @@ inline Counters render(const Scene& sc, uint32_t W, uint32_t H, uint32_t s0, uin
             for (uint32_t x = start_x; x < end_x; x++)
                 for (uint32_t y = 0; y < H; y++) {
                     Vec3 color(0.0, 0.0, 0.0);
-                    for (uint32_t s = s0; s < s0 + n; s++) color += sample_pixel(sc, W, H, x, y, s, seed, max_depth);
+                    for (uint32_t s = s0; s < s0 + n; s++) color += sample_pixel(sc, W, H, x, y, s, seed, max_depth, max_retries);
                     double* a = accum + ((size_t)y * W + x) * 3;
                     a[0] += color.x; a[1] += color.y; a[2] += color.z;
                 }

@@ -29,6 +29,7 @@ def lib():
         L.orc_scene_camera.argtypes = [vp, vp]
         L.orc_trace_primary.argtypes = [vp, u32, u32, dbl, dbl, vp, vp]
         L.orc_render.argtypes = [vp, u32, u32, u32, u32, C.c_int, u64, C.c_int, vp, vp]
+        L.orc_render_ex.argtypes = [vp, u32, u32, u32, u32, C.c_int, u64, C.c_int, C.c_int, vp, vp]
         L.orc_sample_pixel.argtypes = [vp, u32, u32, u32, u32, u32, u64, C.c_int, vp]
         L.orc_resolve.argtypes = [vp, u32, u32, u32, vp]
         L.orc_bvh_dump.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -40,7 +41,7 @@ def lib():
 
 
 COUNTER_NAMES = ("paths", "casts", "prim_tests", "node_visits", "nan_retries", "misses", "depth_exhausted", "flops",
-                 "lambertian", "metal", "dielectric", "light", "isotropic", "frosted")
+                 "lambertian", "metal", "dielectric", "light", "isotropic", "frosted", "dropped")
 
 
 class OracleScene:
@@ -86,11 +87,12 @@ class OracleScene:
         lib().orc_trace_primary(self._h, width, height, float(time), float(medium_xi), ids.ctypes.data, ts.ctypes.data)
         return ids, ts
 
-    def render(self, width, height, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, threads=8, accum=None):
+    def render(self, width, height, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, threads=8, accum=None, max_nan_retries=64):
         if accum is None:
             accum = np.zeros((height, width, 3), dtype=np.float64)
         cnt = np.zeros(16)
-        lib().orc_render(self._h, width, height, spp_begin, spp_count, max_depth, int(seed), threads, accum.ctypes.data, cnt.ctypes.data)
+        lib().orc_render_ex(self._h, width, height, spp_begin, spp_count, max_depth, int(seed), threads, int(max_nan_retries),
+                            accum.ctypes.data, cnt.ctypes.data)
         return accum, dict(zip(COUNTER_NAMES, cnt.tolist()))
 
     def sample_pixel(self, width, height, x, y, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50):

@@ -282,3 +282,30 @@ def test_empty_world_on_the_device(precision, gpu):
         assert (rgb == want).all()
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("no_sort", (False, True))
+def test_nan_retry_cap_and_dropped_samples(no_sort, gpu):
+    # ray_tracing.rs:102-110 retries a NaN sample for ever; the device gives up after max_nan_retries (stats[3], sample = 0).
+    # final_scene produces NaN samples; with a cap of 1 some NaN twice in a row.  Counters and frame against the oracle run
+    # with the same cap.
+    W, H, spp = 48, 48, 24
+    oc = OracleScene("final_scene", 1.0)
+    ref, cnt = oc.render(W, H, 0, spp, threads=8, max_nan_retries=1)
+    assert cnt["dropped"] > 0
+    ds = rt.DeviceScene(rt.HostScene("final_scene", 1.0), 0)
+    try:
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st, max_nan_retries=1, no_sort=no_sort)
+        accepted, casts, retries, dropped = st.cpu().tolist()
+        assert accepted + dropped == W * H * spp
+        assert abs(dropped - cnt["dropped"]) <= 2 and abs(retries - cnt["nan_retries"]) <= 0.01 * cnt["nan_retries"] + 2
+        assert abs(casts - cnt["casts"]) <= 0.005 * cnt["casts"]
+        close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995
+        st.zero_()
+        ds.render_into(torch.zeros_like(acc), 0, spp, precision="f64", stats=st)  # default cap (64): nothing dropped here
+        assert st.cpu().tolist()[3] == 0 and st.cpu().tolist()[0] == W * H * spp
+    finally:
+        ds.close()

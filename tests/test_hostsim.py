@@ -76,8 +76,8 @@ class SimScene:
         self.L.sim_trace_primary(self.h, W, H, time, xi, 1 if precision == "f64" else 0, int(generic), ids.ctypes.data, ts.ctypes.data)
         return ids, ts
 
-    def _params(self, W, H, s0, n, precision, max_depth=50, seed=DEFAULT_SEED):
-        return _ffi.RtRenderParams(W, H, s0, n, max_depth, 64, seed, 1 if precision == "f64" else 0, 0)
+    def _params(self, W, H, s0, n, precision, max_depth=50, seed=DEFAULT_SEED, max_nan_retries=64):
+        return _ffi.RtRenderParams(W, H, s0, n, max_depth, max_nan_retries, seed, 1 if precision == "f64" else 0, 0)
 
     def samples(self, W, H, x, y, s0, n, precision="f64", generic=False):
         out = np.zeros((n, 3))
@@ -86,10 +86,10 @@ class SimScene:
         self.L.sim_sample_pixel(self.h, C.byref(p), x, y, int(generic), out.ctypes.data, C.byref(casts))
         return out, casts.value
 
-    def render(self, W, H, s0, n, precision="f64", generic=False, max_depth=50):
+    def render(self, W, H, s0, n, precision="f64", generic=False, max_depth=50, max_nan_retries=64):
         acc = np.zeros((H, W, 3))
         casts = C.c_uint64(0)
-        p = self._params(W, H, s0, n, precision, max_depth)
+        p = self._params(W, H, s0, n, precision, max_depth, max_nan_retries=max_nan_retries)
         self.L.sim_render(self.h, C.byref(p), int(generic), acc.ctypes.data, C.byref(casts))
         return acc, casts.value
 
@@ -167,6 +167,21 @@ def test_sim_depth_limits(sim):
     assert sc.render(8, 8, 0, 4, max_depth=0)[0].max() == 0.0
     a, _ = sc.render(16, 16, 0, 4, max_depth=1)
     assert set(np.unique(a).tolist()) <= {0.0, 15.0, 30.0, 45.0, 60.0}
+
+
+def test_sim_nan_retry_cap(sim):
+    # ray_tracing.rs:102-110 retries a NaN sample for ever; this build gives up after max_nan_retries and takes the sample as
+    # zero (stats[3]).  final_scene produces NaN samples, and with a cap of 1 some samples NaN twice in a row: same frames,
+    # same casts as the oracle with the same cap — and fewer casts than with the default cap
+    sc = SimScene(sim, "final_scene")
+    oc = OracleScene("final_scene", 1.0)
+    got, casts = sc.render(24, 24, 0, 24, max_nan_retries=1)
+    ref, cnt = oc.render(24, 24, 0, 24, threads=8, max_nan_retries=1)
+    assert cnt["nan_retries"] > 0 and cnt["dropped"] > 0, cnt
+    assert casts == cnt["casts"]
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+    ref64, cnt64 = oc.render(24, 24, 0, 24, threads=8)
+    assert cnt64["dropped"] == 0 and cnt64["casts"] > cnt["casts"] and cnt64["nan_retries"] > cnt["nan_retries"]
 
 
 def test_light_with_empty_range_is_rejected(sim):
