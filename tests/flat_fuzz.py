@@ -139,3 +139,19 @@ def tie_scene(seed):
     # on a grid line, looking along -z: the centre column of an odd-width probe has d.x == 0 exactly
     fs.camera([0.0, 5.0, 3.0 * n + 6.0], [0.0, 2.0, 0.0] if seed % 2 else [0.0, 5.0, 0.0], [0, 1, 0], 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
     return fs
+
+
+def nan_scene():
+    """A scene whose diffuse bounces all come out NaN: the light LIST holds a sphere that encloses the whole scene, and
+    Sphere::pdf_value from inside a sphere takes the square root of a negative number (src/objects.rs:126-137).  Samples that
+    see the floor are retried until the cap and dropped; samples that see the lamp or the sky succeed.  No BVH: the
+    block-sorted kernel renders it."""
+    fs = F.FlatScene()
+    grey = fs.material(F.LAMBERTIAN, fs.solid(0.7, 0.7, 0.7))
+    lamp = fs.material(F.DIFFUSE_LIGHT, fs.solid(4.0, 3.0, 2.0))
+    fs.add_world(fs.rect(1, -3.0, 3.0, -3.0, 3.0, 0.0, 1.0, grey))       # floor (XZ at y = 0)
+    fs.add_world(fs.sphere((0.0, 2.5, 0.0), 0.6, lamp))
+    fs.add_light(fs.sphere((0.0, 1.0, 0.0), 50.0, lamp))                # encloses camera and floor
+    fs.background = [0.1, 0.2, 0.3]
+    fs.camera((0.0, 2.0, -6.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 50.0, 1.0, 0.0, 6.0)
+    return fs

@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import random_scene, tie_scene
+from flat_fuzz import nan_scene, random_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -68,6 +68,18 @@ def test_tie_scene_sim_equals_oracle(sim, seed):
     ref, cnt = oc.render(21, 15, 0, 3, threads=4)
     assert casts == cnt["casts"], (seed, casts, cnt["casts"])
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+
+
+def test_nan_scene_retries_and_drops(sim):
+    # every diffuse bounce is NaN (flat_fuzz.nan_scene): floor samples are retried up to the cap, then dropped
+    host = rt.FlatHostScene(nan_scene())
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    for cap in (2, 5):
+        got, casts = sc.render(16, 16, 0, 3, max_nan_retries=cap)
+        ref, cnt = oc.render(16, 16, 0, 3, threads=4, max_nan_retries=cap)
+        assert cnt["dropped"] > 100 and cnt["nan_retries"] == (cap + 1) * cnt["dropped"]
+        assert casts == cnt["casts"] and np.array_equal(got, ref)
 
 
 def empty_world_scene():

@@ -309,3 +309,26 @@ def test_nan_retry_cap_and_dropped_samples(no_sort, gpu):
         assert st.cpu().tolist()[3] == 0 and st.cpu().tolist()[0] == W * H * spp
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("no_sort", (False, True))
+def test_nan_scene_retries_and_drops_on_device(no_sort, gpu):
+    # tests/flat_fuzz.py: nan_scene — every diffuse bounce is NaN: floor samples are retried up to the cap and dropped, in the
+    # block-sorted kernel (light list, no BVH) and in the persistent one; counters and frame equal the oracle's with the same cap
+    from flat_fuzz import nan_scene
+    host = rt.FlatHostScene(nan_scene())
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    W, H, spp = 40, 40, 6
+    try:
+        for cap in (1, 3):
+            ref, cnt = oc.render(W, H, 0, spp, threads=8, max_nan_retries=cap)
+            acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+            st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            ds.render_into(acc, 0, spp, precision="f64", stats=st, max_nan_retries=cap, no_sort=no_sort)
+            accepted, casts, retries, dropped = st.cpu().tolist()
+            assert dropped == cnt["dropped"] > 1000 and retries == cnt["nan_retries"] == (cap + 1) * dropped
+            assert accepted == W * H * spp - dropped and casts == cnt["casts"]
+            assert np.allclose(acc.cpu().numpy(), ref, rtol=2e-6, atol=0)
+    finally:
+        ds.close()
