@@ -71,8 +71,22 @@ def build_host(force=False):
     return LIB_HOST
 
 
+LAUNCHER = os.path.join(PKG, "rt_render")
+
+
+def build_launcher(force=False):
+    """The native launcher (host/rt_render_main.cpp): C++ against include/rt_host.h + include/rt_hip.h only, linked to the
+    two libraries beside it (rpath $ORIGIN)."""
+    src = os.path.join(HOST, "rt_render_main.cpp")
+    deps = [src, LIB_HOST, LIB_HIP, os.path.join(ROOT, "include", "rt_hip.h"), os.path.join(ROOT, "include", "rt_host.h")]
+    if force or _newer(LAUNCHER, deps):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", LAUNCHER, src, "-L" + PKG, "-lrt_host", "-lrt_hip",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + PKG + ":/opt/rocm/lib"])
+    return LAUNCHER
+
+
 def build_all(force=False):
-    return build_hip(force), build_host(force)
+    return build_hip(force), build_host(force), build_launcher(force)
 
 
 if __name__ == "__main__":

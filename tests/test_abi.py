@@ -117,3 +117,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_ffi, "LIB_HIP", "/nonexistent/librt_hip.so")
     with pytest.raises(rt.RtError, match="no CPU fallback"):
         _ffi.hip()
+
+
+def test_native_launcher_is_built_against_the_two_libraries_only():
+    # ray-tracing_amd/rt_render (host/rt_render_main.cpp): the C++ launcher a maintainer can run without Python.  Here (no GPU):
+    # it exists, knows the scenes, rejects nonsense, and links librt_host + librt_hip — not the oracle.
+    exe = os.path.join(os.path.dirname(_ffi.LIB_HIP), "rt_render")
+    assert os.path.exists(exe), "python -c 'import ray_tracing_amd as rt; rt.build_all()' builds it"
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0
+    for name in rt.SCENES:
+        assert name in r.stdout
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 1 and "unknown option" in r.stderr
+    r = subprocess.run([exe, "--width", "1"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 1
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "librt_host.so" in needed and "librt_hip.so" in needed and "oracle" not in needed and "$ORIGIN" in needed

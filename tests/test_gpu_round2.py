@@ -332,3 +332,51 @@ def test_nan_scene_retries_and_drops_on_device(no_sort, gpu):
             assert np.allclose(acc.cpu().numpy(), ref, rtol=2e-6, atol=0)
     finally:
         ds.close()
+
+
+def _png_pixels(path):
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, w, h = 8, b"", 0, 0
+    while at < len(data):
+        n, tag = struct.unpack(">I", data[at:at + 4])[0], data[at + 4:at + 8]
+        body = data[at + 8:at + 8 + n]
+        assert zlib.crc32(tag + body) & 0xFFFFFFFF == struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0]
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 2)
+        elif tag == b"IDAT":
+            idat += body
+        at += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * 3)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("name,W,H,spp", (("cornell_box", 72, 56, 12), ("random_scene", 61, 35, 5)))
+def test_native_launcher_equals_python_path(name, W, H, spp, scenes, tmp_path):
+    # ray-tracing_amd/rt_render (host/rt_render_main.cpp): C++ against the two C headers only — no Python, no torch in that
+    # process.  Same scene, seed and sample ranges -> the same 8-bit image as renderer.render + resolve + write_png.
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray-tracing_amd", "rt_render")
+    assert os.path.exists(exe), "build the launcher: python -c 'import ray_tracing_amd as rt; rt.build_all()'"
+    out = str(tmp_path / "native.png")
+    r = subprocess.run([exe, "--scene", name, "--width", str(W), "--height", str(H), "--spp", str(spp), "--spp-per-launch", "4", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["scene"] == name and rec["n_gpus"] == 1 and rec["dropped_samples"] == 0
+    ds = scenes(name, W / H)
+    st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    acc = rt.render(ds, W, H, spp, precision="f64", spp_per_launch=4, stats=st)
+    want = rt.resolve(acc, spp).cpu().numpy()
+    assert np.array_equal(_png_pixels(out), want)
+    assert abs(rec["casts_per_sample"] - st[1].item() / st[0].item()) < 1e-3
+    ref = str(tmp_path / "python.png")
+    rt.write_png(ref, rt.resolve(acc, spp))
+    assert np.array_equal(_png_pixels(ref), want)
+    # errors are messages and exit codes
+    r = subprocess.run([exe, "--scene", "no_such_scene", "--out", out], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "scene" in r.stderr
