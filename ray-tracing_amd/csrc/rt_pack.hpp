@@ -337,21 +337,29 @@ template <class T> void convert_instances(const RtInstance* ins, uint32_t n, std
 }
 
 
-// Light primitives that Object::random samples by gen_range need a non-empty range: rand's
-// gen_range panics on low >= high in the reference; here it is a validation error.
+// Light primitives that Object::random samples by gen_range, and the camera's shutter interval, need a range the
+// generator can serve: rand 0.7.3's gen_range panics on low >= high and on a non-finite width in the reference; here both
+// are validation errors — in BOTH arithmetic modes, because the device redraws until a value falls below `high`
+// (rt_device.hpp: Rng::gen_range) and would never stop on a range that is empty or not finite after rounding to f32.
+inline bool samplable_range(double lo, double hi) {
+    const float flo = (float)lo, fhi = (float)hi;
+    return lo < hi && std::isfinite(hi - lo) && flo < fhi && std::isfinite(fhi - flo);  // (false for NaN; +-inf fail the widths)
+}
 inline int validate_light_ranges(const RtSceneDesc* d) {
+    const char* why = " has an empty or non-finite range (gen_range needs low < high, both finite, also after rounding to f32)";
     for (uint32_t i = 0; i < d->n_lights; i++) {
         const RtInstance& in = d->lights[i];
         if (in.is_medium || in.geom_kind != RT_GEOM_PRIM) continue;
         const RtPrim& p = d->prims[in.geom_index];
         if (p.kind >= RT_PRIM_RECT_XY && p.kind <= RT_PRIM_RECT_YZ) {
-            if (!(p.d[0] < p.d[1]) || !(p.d[2] < p.d[3])) return fail(RT_ERR_INVALID, "light rect has an empty range (gen_range needs low < high)");
+            if (!samplable_range(p.d[0], p.d[1]) || !samplable_range(p.d[2], p.d[3])) return fail(RT_ERR_INVALID, std::string("light rect") + why);
         } else if (p.kind == RT_PRIM_CUBOID) {
             for (int k = 0; k < 3; k++)
-                if (!(p.d[k] < p.d[3 + k])) return fail(RT_ERR_INVALID, "light cuboid has an empty range (gen_range needs low < high)");
+                if (!samplable_range(p.d[k], p.d[3 + k])) return fail(RT_ERR_INVALID, std::string("light cuboid") + why);
         }
     }
-    if (!(d->camera.t1 < d->camera.t2)) return fail(RT_ERR_INVALID, "camera shutter needs t1 < t2 (gen_range, src/camera.rs:63)");
+    if (!samplable_range(d->camera.t1, d->camera.t2))
+        return fail(RT_ERR_INVALID, "camera shutter needs t1 < t2, both finite, also after rounding to f32 (gen_range, src/camera.rs:63)");
     return RT_OK;
 }
 

@@ -185,14 +185,43 @@ def test_sim_nan_retry_cap(sim):
 
 
 def test_light_with_empty_range_is_rejected(sim):
+    # gen_range(low, high) panics in the reference on low >= high and on a non-finite width; the device would redraw for ever.
+    # Rejected at scene creation, for both arithmetic modes (a range that is empty only after rounding to f32 counts)
     hs = rt.HostScene("cornell_box", 1.0)
-    bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
-    prims = (_ffi.RtPrim * bad.n_prims)(*[bad.prims[i] for i in range(bad.n_prims)])
-    li = bad.lights[0].geom_index
-    prims[li].d[1] = prims[li].d[0]  # x2 == x1: gen_range(low, high) panics in the reference
-    bad.prims = C.cast(prims, C.POINTER(_ffi.RtPrim))
-    rc = C.c_int()
-    assert not sim.sim_scene_create(C.byref(bad), C.byref(rc)) and rc.value == 1 and b"empty range" in sim.sim_last_error()
+    li = hs.desc.lights[0].geom_index
+
+    def create(mutate):
+        bad = _ffi.RtSceneDesc.from_buffer_copy(hs.desc)
+        prims = (_ffi.RtPrim * bad.n_prims)(*[bad.prims[i] for i in range(bad.n_prims)])
+        bad.prims = C.cast(prims, C.POINTER(_ffi.RtPrim))
+        mutate(bad, prims)
+        rc = C.c_int()
+        h = sim.sim_scene_create(C.byref(bad), C.byref(rc))
+        return h, rc.value, sim.sim_last_error()
+
+    def set_d(k, v):
+        def f(bad, prims):
+            prims[li].d[k] = v
+        return f
+
+    x1 = hs.desc.prims[li].d[0]
+    for mutate in (set_d(1, x1), set_d(1, x1 - 1.0), set_d(1, float("nan")), set_d(0, float("-inf")), set_d(1, float("inf")),
+                   set_d(1, x1 * (1.0 + 1e-12)),           # non-empty in f64, empty in f32
+                   set_d(3, 1e300)):                        # finite in f64, infinite in f32
+        h, rc, msg = create(mutate)
+        assert not h and rc == 1 and b"range" in msg, msg
+
+    def shutter(t1, t2):
+        def f(bad, prims):
+            bad.camera.t1, bad.camera.t2 = t1, t2
+        return f
+
+    for mutate in (shutter(0.5, 0.5), shutter(1.0, 0.0), shutter(0.0, float("inf")), shutter(float("nan"), 1.0), shutter(0.0, 1e-60)):
+        h, rc, msg = create(mutate)
+        assert not h and rc == 1 and b"shutter" in msg, msg
+    h, rc, msg = create(shutter(0.25, 0.75))
+    assert h and rc == 0
+    sim.sim_scene_destroy(h)
 
 
 @pytest.mark.parametrize("name", ("random_scene", "final_scene", "random_scene_light"))
