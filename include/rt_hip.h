@@ -156,7 +156,7 @@ typedef struct RtBvh {
 /* src/camera.rs:7-18 */
 typedef struct RtCamera {
     double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
-    double lens_radius, t1, t2;
+    double lens_radius, t1, t2;   /* shutter: t1 < t2, both finite, also after rounding to f32 (gen_range, src/camera.rs:63) */
 } RtCamera;
 
 /* The flattened scene = the 4-tuple returned by the scenes.rs constructors. */
@@ -169,7 +169,8 @@ typedef struct RtSceneDesc {
     uint32_t n_images;    const RtImage* images;
     uint32_t n_xforms;    const RtXform* xforms;
     uint32_t n_world;     const RtInstance* world;  /* ObjectList order is semantically relevant; 0 objects is a valid (all-background) world */
-    uint32_t n_lights;    const RtInstance* lights; /* 0 <=> lights = None */
+    uint32_t n_lights;    const RtInstance* lights; /* 0 <=> lights = None.  Rectangle / cuboid lights need low < high on every sampled
+                                                       axis, finite, also after rounding to f32 (the reference's gen_range panics otherwise) */
     RtBvh bvh;
     double background[3];
     RtCamera camera;
