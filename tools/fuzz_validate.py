@@ -112,11 +112,12 @@ def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
     test_hostsim._build()
     bad, tally = [], {"python": 0, "rejected": 0, "accepted": 0}
-    r, w = os.pipe()
+    import tempfile
+    log = tempfile.NamedTemporaryFile(prefix="fuzz_validate_", suffix=".log", delete=False)  # (children append one line each)
+    w = log.fileno()
     for seed in range(first, last):
         pid = os.fork()
         if pid == 0:
-            os.close(r)
             signal.alarm(20)
             L = C.CDLL(test_hostsim.SIM_LIB)
             vp, u32, dbl = C.c_void_p, C.c_uint32, C.c_double
@@ -136,8 +137,10 @@ def main():
         if status != 0:
             sig = status & 0x7F
             bad.append((seed, f"signal {sig}" if sig else f"exit {status >> 8}"))
-    os.close(w)
-    for line in os.fdopen(r).read().splitlines():
+    log.close()
+    lines = open(log.name).read().splitlines()
+    os.unlink(log.name)
+    for line in lines:
         parts = line.split(" ", 2)
         if parts[1] in tally:
             tally[parts[1]] += 1
