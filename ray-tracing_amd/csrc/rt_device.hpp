@@ -978,6 +978,74 @@ template <class T> struct Hit {
     int inst, prim, side;  // side 7 = ConstantMedium event
 };
 
+// Both boundary searches of a ConstantMedium (src/objects.rs:529-536: boundary.hit(-inf, inf), then boundary.hit(t1 + 0.0001, inf))
+// on ONE sphere or cuboid.  The roots of the sphere / the plane distances and in-face tests of the six sides do not depend on the
+// search range: they are computed once, and each search only redoes its range comparisons — the same comparisons, in the same
+// order, on the same values as two separate prim_hit calls (sphere_hit; the cuboid loop of prim_hit with its shrinking `closest`).
+// Returns how many of the two searches found a hit (the second is not made when the first fails); ta / tb: their distances.
+// cornell_smoke: 12 of the 30 rectangle tests of a cast drop out; final_scene: 2 of its 11 sphere tests.
+template <class T, uint32_t F>
+__device__ inline int boundary_two(const DPrim<T>& p, V3<T> o, V3<T> d, T time, T& ta, T& tb) {
+    const T lo0 = -Lim<T>::max(), hi = Lim<T>::max();
+    if ((has<F>(F_SPHERE) || has<F>(F_MOVING)) && p.kind <= 1) {
+        V3<T> center(p.d);
+        T radius = p.d[3];
+        if (has<F>(F_MOVING) && (!has<F>(F_SPHERE) || p.kind == 1)) { center = moving_center(p, time); radius = p.d[8]; }
+        V3<T> oc = o - center;
+        T a = dot(d, d);
+        T half_b = dot(oc, d);
+        T c = dot(oc, oc) - radius * radius;
+        T discriminant = half_b * half_b - a * c;
+        if (!(discriminant > T(0))) return 0;
+        T sq = sqrt_r(discriminant);
+        const PlainDiv<T> inv_a(a);
+        const T r1 = inv_a.div(-half_b - sq), r2 = inv_a.div(-half_b + sq);
+        bool h1 = (r1 > lo0) & (r1 < hi), h2 = (r2 > lo0) & (r2 < hi);
+        if (!(h1 | h2)) return 0;
+        ta = h1 ? r1 : r2;
+        const T lo1 = ta + T(0.0001);
+        h1 = (r1 > lo1) & (r1 < hi); h2 = (r2 > lo1) & (r2 < hi);
+        if (!(h1 | h2)) return 1;
+        tb = h1 ? r1 : r2;
+        return 2;
+    }
+    if (has<F>(F_CUBOID) && p.kind == 5) {
+        T ts[6];
+        bool in[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {  // rect_hit's arithmetic, once per side
+            int axis; T a1, a2, b1, b2, k, face;
+            cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
+            const T ok = axis == 0 ? o.z : (axis == 1 ? o.y : o.x), dk = axis == 0 ? d.z : (axis == 1 ? d.y : d.x);
+            const T oa = axis == 2 ? o.y : o.x, da = axis == 2 ? d.y : d.x;
+            const T ob = axis == 0 ? o.y : o.z, db = axis == 0 ? d.y : d.z;
+            const T t = (k - ok) / dk;
+            const T a = oa + t * da;
+            const T b = ob + t * db;
+            ts[i] = t;
+            in[i] = (a >= a1) & (a <= a2) & (b >= b1) & (b <= b2);
+        }
+        int found = 0;
+        T lo = lo0;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {  // the six sides in tuple order with a shrinking `closest` (src/objects.rs:458-485), per search
+            bool any = false;
+            T closest = hi;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const bool h = in[i] & (ts[i] >= lo) & (ts[i] <= closest);
+                closest = h ? ts[i] : closest;
+                any |= h;
+            }
+            if (!any) return found;
+            found++;
+            if (s == 0) { ta = closest; lo = ta + T(0.0001); } else tb = closest;
+        }
+        return found;
+    }
+    return -1;  // another kind of boundary: the caller searches twice through geom_hit
+}
+
 // src/objects.rs:38-48 (ObjectList::hit over the world) with Translate/RotateY wrappers and
 // ConstantMedium (src/objects.rs:529-556) folded in.  The instance loop is wave-uniform.  A medium
 // runs the boundary search twice through the SAME geom_hit call site (pass 0: (-max, max),
@@ -1014,6 +1082,35 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
 #endif
         const bool med = has<F>(F_MEDIUM) && in.is_medium;
         T ta = T(0);
+        // what a medium does once both boundary distances are known (src/objects.rs:537-556)
+        auto medium_event = [&](T tb) {
+            T t1 = ta < t_min ? t_min : ta;
+            if (tb > closest) tb = closest;
+            if (t1 < tb) {
+                T len = length(ray.dir);
+                T distance_inside_boundary = (tb - t1) * len;
+                T hit_distance = -(T(1) / in.density) * rlog(medium_xi<T>(mxi));
+                if (hit_distance <= distance_inside_boundary) {
+                    const T t = t1 + hit_distance / len;
+                    any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
+                    int first = (int)in.geom_index;  // boundary's first primitive in pre-order
+                    if (has<F>(F_BVH) && in.geom_kind != 0) {
+                        int e = sc.bvh_root_entry[in.geom_index];
+                        while (sc.bvh[e].prim < 0) e++;
+                        first = sc.bvh[e].prim;
+                    }
+                    hit.prim = first;
+                }
+            }
+        };
+        if (has<F>(F_MEDIUM) && med && in.geom_kind == 0) {  // a single sphere or cuboid as boundary: both searches share their arithmetic
+            T tb = T(0);
+            const int n = boundary_two<T, F>(sc.prims[in.geom_index], o, d, ray.time, ta, tb);
+            if (n >= 0) {
+                if (n == 2) medium_event(tb);
+                continue;
+            }
+        }
         const int passes = med ? 2 : 1;
 #pragma nounroll
         for (int pass = 0; pass < passes; pass++) {
@@ -1026,25 +1123,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             } else if (has<F>(F_MEDIUM)) {
                 if (!h) break;
                 if (pass == 0) { ta = t; continue; }
-                T tb = t;
-                T t1 = ta < t_min ? t_min : ta;
-                if (tb > closest) tb = closest;
-                if (t1 < tb) {
-                    T len = length(ray.dir);
-                    T distance_inside_boundary = (tb - t1) * len;
-                    T hit_distance = -(T(1) / in.density) * rlog(medium_xi<T>(mxi));
-                    if (hit_distance <= distance_inside_boundary) {
-                        t = t1 + hit_distance / len;
-                        any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
-                        int first = (int)in.geom_index;  // boundary's first primitive in pre-order
-                        if (has<F>(F_BVH) && in.geom_kind != 0) {
-                            int e = sc.bvh_root_entry[in.geom_index];
-                            while (sc.bvh[e].prim < 0) e++;
-                            first = sc.bvh[e].prim;
-                        }
-                        hit.prim = first;
-                    }
-                }
+                medium_event(t);
             }
         }
     }
