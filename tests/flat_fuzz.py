@@ -155,3 +155,56 @@ def nan_scene():
     fs.background = [0.1, 0.2, 0.3]
     fs.camera((0.0, 2.0, -6.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 50.0, 1.0, 0.0, 6.0)
     return fs
+
+
+def medium_scene(seed):
+    """ConstantMedium with every kind of boundary the flat form can express: a sphere, a MOVING sphere, a cuboid, a single
+    rectangle (never scatters: the second boundary search finds nothing), and a BVH of spheres and cuboids — some behind
+    wrapper chains — over a lit floor.  The device takes two routes through a medium (rt_device.hpp: boundary_two for one
+    sphere / cuboid, two searches through geom_hit for everything else); this scene set walks both."""
+    rng = random.Random(5000 + seed)
+    U = rng.uniform
+    fs = F.FlatScene()
+    grey = fs.material(F.LAMBERTIAN, fs.solid(0.6, 0.6, 0.6))
+    lamp = fs.material(F.DIFFUSE_LIGHT, fs.solid(5.0, 5.0, 5.0))
+    glass = fs.material(F.DIELECTRIC, ref_idx=1.5)
+    fs.add_world(fs.rect(1, -20, 20, -20, 20, -1.0, 1.0, grey))
+    lr = fs.rect(1, -2.0, 2.0, -2.0, 2.0, 7.0, -1.0, lamp)
+    fs.add_world(lr)
+    if seed % 2 == 0:
+        fs.add_light(lr)
+    fs.add_world(fs.sphere([U(-4, 4), 0.5, U(-4, 4)], 1.0, fs.material(F.METAL, albedo=(0.8, 0.7, 0.6), fuzz=0.1)))
+
+    def chain():
+        c = rng.random()
+        if c < 0.4:
+            return ()
+        if c < 0.7:
+            return (("t", (U(-2, 2), U(0, 1), U(-2, 2))),)
+        return (("t", (U(-2, 2), U(0, 1), U(-2, 2))), ("r", U(-45, 45)))
+
+    kinds = ["sphere", "moving", "cuboid", "rect", "bvh"]
+    rng.shuffle(kinds)
+    for kind in kinds[:3 + seed % 3]:
+        iso = fs.material(F.ISOTROPIC, texture=fs.solid(U(0.2, 1), U(0.2, 1), U(0.2, 1)))
+        c = [U(-4, 4), U(0.5, 2.5), U(-4, 4)]
+        if kind == "sphere":
+            fs.add_world(fs.sphere(c, U(0.8, 2.0), glass), chain=chain(), medium=(U(0.1, 1.5), iso))
+        elif kind == "moving":
+            c2 = [c[0] + U(-1, 1), c[1] + U(-0.3, 0.3), c[2] + U(-1, 1)]
+            fs.add_world(fs.moving_sphere(c, c2, 0.0, 1.0, U(0.8, 1.8), glass), chain=chain(), medium=(U(0.1, 1.5), iso))
+        elif kind == "cuboid":
+            fs.add_world(fs.cuboid([c[0] - 1, c[1] - 1, c[2] - 1], [c[0] + U(0.5, 1.5), c[1] + U(0.5, 1.5), c[2] + U(0.5, 1.5)], grey),
+                         chain=chain(), medium=(U(0.1, 1.5), iso))
+        elif kind == "rect":
+            fs.add_world(fs.rect(rng.randrange(3), -1.5, 1.5, -1.5, 1.5, U(0, 2), 1.0, grey), chain=chain(), medium=(U(0.1, 1.5), iso))
+        else:
+            ids = []
+            for _ in range(rng.randrange(2, 7)):
+                q = [c[0] + U(-1.5, 1.5), c[1] + U(-0.5, 1.0), c[2] + U(-1.5, 1.5)]
+                ids.append(fs.sphere(q, U(0.4, 1.0), glass) if rng.random() < 0.6 else
+                           fs.cuboid([q[0] - 0.5, q[1] - 0.5, q[2] - 0.5], [q[0] + 0.5, q[1] + 0.6, q[2] + 0.7], grey))
+            fs.add_world(fs.build_bvh(ids, rng), bvh=True, chain=chain() if rng.random() < 0.5 else (), medium=(U(0.1, 1.5), iso))
+    fs.background = [0.3, 0.4, 0.6]
+    fs.camera([U(9, 13), U(2, 5), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, rng.choice([0.0, 0.15]), 13.0, 0.0, 1.0)
+    return fs

@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import nan_scene, random_scene, tie_scene
+from flat_fuzz import medium_scene, nan_scene, random_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -68,6 +68,27 @@ def test_tie_scene_sim_equals_oracle(sim, seed):
     ref, cnt = oc.render(21, 15, 0, 3, threads=4)
     assert casts == cnt["casts"], (seed, casts, cnt["casts"])
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_medium_scene_sim_equals_oracle(sim, seed):
+    # ConstantMedium around every kind of boundary (sphere, moving sphere, cuboid, single rectangle, BVH; wrapper chains): both
+    # routes of the device through a medium (boundary_two / two searches through geom_hit) against the oracle
+    host = rt.FlatHostScene(medium_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    W, H = 36, 28
+    for tm, xi in ((0.0, 0.5), (0.7, 0.03), (0.3, 0.97)):
+        for generic in (False, True):
+            ids, ts = sc.primary(W, H, tm, xi, "f64", generic)
+            oi, ot = oc.trace_primary(W, H, tm, xi)
+            assert np.array_equal(ids, oi), (seed, tm, generic, int((ids != oi).sum()))
+            assert np.array_equal(ts, ot)
+    got, casts = sc.render(20, 16, 0, 4)
+    ref, cnt = oc.render(20, 16, 0, 4, threads=4)
+    assert cnt["isotropic"] > 0, "the scene must actually scatter inside a medium"
+    assert casts == cnt["casts"], (seed, casts, cnt["casts"])
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True), (seed, np.nanmax(np.abs(got - ref)))
 
 
 def test_nan_scene_retries_and_drops(sim):

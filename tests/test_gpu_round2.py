@@ -380,3 +380,30 @@ def test_native_launcher_equals_python_path(name, W, H, spp, scenes, tmp_path):
     # errors are messages and exit codes
     r = subprocess.run([exe, "--scene", "no_such_scene", "--out", out], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "scene" in r.stderr
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_medium_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: medium_scene — ConstantMedium around a sphere, a moving sphere, a cuboid, a single rectangle and a BVH,
+    # some behind wrapper chains: both routes of the device through a medium (boundary_two / two searches through geom_hit)
+    from flat_fuzz import medium_scene
+    host = rt.FlatHostScene(medium_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        W, H = 56, 40
+        for tm, xi in ((0.0, 0.5), (0.7, 0.03)):
+            ids, ts = ds.trace_primary(W, H, tm, xi, "f64")
+            oi, ot = oc.trace_primary(W, H, tm, xi)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot)
+        spp = 4
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        assert cnt["isotropic"] > 0
+        for no_sort in (False, True):
+            acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+            st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            ds.render_into(acc, 0, spp, precision="f64", stats=st, no_sort=no_sort)
+            close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+            assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
