@@ -208,3 +208,31 @@ def medium_scene(seed):
     fs.background = [0.3, 0.4, 0.6]
     fs.camera([U(9, 13), U(2, 5), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, rng.choice([0.0, 0.15]), 13.0, 0.0, 1.0)
     return fs
+
+
+def odd_lights_scene(seed):
+    """A light LIST with members that keep the Object trait's defaults (src/objects.rs:22-27: pdf_value = 0, random = (1,0,0)):
+    a BvhNode, a ConstantMedium and a MovingSphere, beside an ordinary rectangle and a translated sphere."""
+    rng = random.Random(7000 + seed)
+    U = rng.uniform
+    fs = F.FlatScene()
+    grey = fs.material(F.LAMBERTIAN, fs.solid(0.7, 0.6, 0.5))
+    lamp = fs.material(F.DIFFUSE_LIGHT, fs.solid(6.0, 5.0, 4.0))
+    glass = fs.material(F.DIELECTRIC, ref_idx=1.5)
+    iso = fs.material(F.ISOTROPIC, texture=fs.solid(0.9, 0.9, 0.9))
+    fs.add_world(fs.rect(1, -15, 15, -15, 15, 0.0, 1.0, grey))
+    lr = fs.rect(1, -1.5, 1.5, -1.5, 1.5, 6.0, -1.0, lamp)
+    fs.add_world(lr); fs.add_light(lr)
+    gs = fs.sphere([0.0, 1.0, 0.0], 1.0, glass)
+    ch = (("t", (U(-3, 3), 0.0, U(-3, 3))),)
+    fs.add_world(gs, chain=ch); fs.add_light(gs, chain=ch)
+    ids = [fs.sphere([U(-5, 5), U(0.5, 1.5), U(-5, 5)], U(0.4, 0.9), grey) for _ in range(rng.randrange(3, 9))]
+    root = fs.build_bvh(ids, rng)
+    fs.add_world(root, bvh=True); fs.add_light(root, bvh=True)
+    fog = fs.sphere([U(-3, 3), 1.5, U(-3, 3)], 1.5, glass)
+    fs.add_world(fog, medium=(0.4, iso)); fs.add_light(fog, medium=(0.4, iso))
+    ms = fs.moving_sphere([3.0, 1.0, -3.0], [3.5, 1.2, -3.0], 0.0, 1.0, 0.8, lamp)
+    fs.add_world(ms); fs.add_light(ms)
+    fs.background = [0.05, 0.05, 0.1]
+    fs.camera([U(8, 12), U(3, 6), U(8, 12)], [0, 1.0, 0], [0, 1, 0], 40.0, 1.0, 0.0, 12.0, 0.0, 1.0)
+    return fs

@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import medium_scene, nan_scene, random_scene, tie_scene
+from flat_fuzz import medium_scene, nan_scene, odd_lights_scene, random_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -89,6 +89,21 @@ def test_medium_scene_sim_equals_oracle(sim, seed):
     assert cnt["isotropic"] > 0, "the scene must actually scatter inside a medium"
     assert casts == cnt["casts"], (seed, casts, cnt["casts"])
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True), (seed, np.nanmax(np.abs(got - ref)))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_odd_lights_scene_sim_equals_oracle(sim, seed):
+    # light-list members that keep the Object trait's defaults (BvhNode, ConstantMedium, MovingSphere: pdf_value 0, random (1,0,0))
+    host = rt.FlatHostScene(odd_lights_scene(seed))
+    assert host.desc.n_lights == 5
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    got, casts = sc.render(24, 18, 0, 6)
+    ref, cnt = oc.render(24, 18, 0, 6, threads=4)
+    assert casts == cnt["casts"], (seed, casts, cnt["casts"])
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True), (seed, np.nanmax(np.abs(got - ref)))
+    s1, _ = sc.samples(24, 18, 11, 7, 0, 24)
+    assert np.allclose(s1, oc.sample_pixel(24, 18, 11, 7, 0, 24), rtol=RAD_RTOL, atol=0, equal_nan=True)
 
 
 def test_nan_scene_retries_and_drops(sim):

@@ -407,3 +407,24 @@ def test_medium_scene_gpu_equals_oracle(seed, gpu):
             assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_odd_lights_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: odd_lights_scene — a light list with a BvhNode, a ConstantMedium and a MovingSphere (the Object trait's
+    # defaults: pdf_value 0, random (1,0,0)) beside a rectangle and a translated sphere
+    from flat_fuzz import odd_lights_scene
+    host = rt.FlatHostScene(odd_lights_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        W, H, spp = 48, 36, 6
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+        assert int(st[2]) == cnt["nan_retries"] or abs(int(st[2]) - cnt["nan_retries"]) <= 0.02 * cnt["nan_retries"] + 2
+    finally:
+        ds.close()
