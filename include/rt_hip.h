@@ -214,7 +214,9 @@ int rt_scene_destroy(RtScene* scene);
  * ray.time = time; every ConstantMedium uses xi = medium_xi instead of a random draw.
  * Any finite `time` is accepted.  Inside [min(0, camera.t1), max(1, camera.t2)] BVH leaves of moving spheres are
  * culled by their time-hull boxes; outside that range the leaf culling is switched off (every reached leaf is
- * tested exactly), so results stay exact, only slower.
+ * tested exactly).  At ray times for which the description's node boxes do not contain their moving spheres (the
+ * reference builds them for (0, 1), bvh.rs:85-111) the reference's loose per-axis box test still reaches some of
+ * those spheres: the walk then takes every node decision with the reference's own test.  Exact either way, only slower.
  * d_ids[y*W+x] = prim*8 + side (side: cuboid face 0..5, 7 = medium event) or -1 on a miss;
  * d_t[y*W+x] = hit distance (f64 even in RT_F32 mode) or -1. */
 int rt_trace_primary(RtScene* scene, uint32_t width, uint32_t height, double time, double medium_xi,

@@ -120,6 +120,8 @@ template <class T> struct DScene {
     uint32_t n_perlins, n_perlin_lds;
     unsigned long long* tex_cache;    // -DRT_TEX_LDS_CACHE=<entries> builds: LDS texel cache of the render kernel (else unused)
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
+    T node_cull_lo, node_cull_hi;   // ray times at which every moving sphere lies inside all its ancestors' boxes in the REFERENCE's
+                                    // trees (rt_pack.hpp); outside, walk_run may not skip a node on geometric grounds
     uint32_t n_world, n_lights, n_materials;
     T background[3];
     DCamera<T> cam;
@@ -700,7 +702,7 @@ __device__ inline DBvhLite lds_entry(const DBvhLite* table, int i) {
 template <class T> struct Walk {
     int i, end;        // next entry, one past the instance's subtree
     T closest, t_min;
-    bool any, leaf_cull;
+    bool any, leaf_cull, node_cull;
     int prim, side;
     float B;           // largest |coordinate| of the tree's root box
     RayF r;            // per-ray constants of the first-level box classification
@@ -731,6 +733,11 @@ __device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T
 #else
     w.leaf_cull = time >= sc.time_lo && time <= sc.time_hi;
 #endif
+    // "Nothing inside this box can be hit" (class 0 of the node classification) lets walk_run skip a node the reference's loose
+    // test would enter — harmless only while the primitives below the node ARE inside its box.  The reference builds its boxes
+    // for the times it is given (bvh.rs:85-111, called with 0.0, 1.0); a moving sphere leaves them at ray times outside.
+    // Then every node decision is the reference's own test.
+    w.node_cull = time >= sc.node_cull_lo && time <= sc.node_cull_hi;
 }
 // Continue the walk.  "while-while" form with three kinds of step, each run for all lanes that want it before the
 // next kind runs, so that box tests, the rare undecided nodes and the primitive tests are not serialised against
@@ -771,7 +778,7 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
                 i = i + 1;  // certainly missed: next entry
                 continue;
             }
-            if (c == 2) { undecided = true; break; }
+            if (c == 2 || (c == 0 && !w.node_cull)) { undecided = true; break; }
             i = c == 1 ? i + 1 : e.skip;
         }
         RT_PCE(2);
@@ -779,7 +786,7 @@ __device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> 
         if (undecided) {
             int c = 2;
             const DBvhEntry<T>& ex = sc.bvh[i];
-            if (sizeof(T) == 8) {  // second level: f64 ray against the exact box (its ray constants are built here: the step is rare)
+            if (sizeof(T) == 8 && w.node_cull) {  // second level: f64 ray against the exact box (its ray constants are built here: the step is rare)
                 RT_SIM_COUNT(5);
                 RayR<T> r2;
                 ray_consts<T, T>(r2, o, d, w.t_min, (T)w.B, T(1.4210854715202004e-14));  // 2^-46: f64 rounding of differences and products

@@ -522,8 +522,41 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
             }
         }
     }
+    // Ray times at which every moving sphere of every reference tree lies inside ALL its ancestors' boxes (with a slack far
+    // below the node classification's own margin): walk_run's geometric node culling is valid exactly there (rt_device.hpp:
+    // walk_begin).  Boxes built by the reference for (0, 1) give [0, 1]; trees without moving spheres give every time.
+    double cull_lo = -1.7976931348623157e308, cull_hi = 1.7976931348623157e308;
+    {
+        std::vector<int32_t> open;
+        for (int32_t e = 0; e < (int32_t)h.bvh.size(); e++) {
+            while (!open.empty() && h.bvh[open.back()].skip <= e) open.pop_back();
+            const DBvhEntry<T>& en = h.bvh[e];
+            if (en.prim < 0) { open.push_back(e); continue; }
+            const RtPrim& p = d->prims[en.prim];
+            if (p.kind != RT_PRIM_MOVING_SPHERE) continue;
+            const double r = std::fabs(p.d[8]), den = p.d[7] - p.d[6], t0 = p.d[6];
+            for (int32_t a : open) {
+                for (int k = 0; k < 3; k++) {
+                    const double mn = (double)h.bvh[a].mn[k], mx = (double)h.bvh[a].mx[k];
+                    const double slack = 1e-7 * (std::fabs(mn) + std::fabs(mx) + r + 1.0);
+                    const double v = (p.d[3 + k] - p.d[k]) / den;            // centre(t) = c1 + v (t - t0)
+                    const double L = mn - slack + r - p.d[k], U = mx + slack - r - p.d[k];  // L <= v (t - t0) <= U
+                    double lo, hi;
+                    if (v > 0.0) { lo = t0 + L / v; hi = t0 + U / v; }
+                    else if (v < 0.0) { lo = t0 + U / v; hi = t0 + L / v; }
+                    else if (v == 0.0 && L <= 0.0 && 0.0 <= U) continue;      // does not move on this axis and fits
+                    else { lo = 1.0; hi = 0.0; }                             // never inside (or NaN): no time qualifies
+                    if (!(lo <= hi)) { lo = 1.0; hi = 0.0; }
+                    cull_lo = std::fmax(cull_lo, lo); cull_hi = std::fmin(cull_hi, hi);
+                }
+            }
+        }
+        if (!(cull_lo <= cull_hi)) { cull_lo = 1.0; cull_hi = 0.0; }  // empty: no ray time qualifies
+    }
     DScene<T>& out = h.view;
     out.time_lo = (T)time_lo; out.time_hi = (T)time_hi;
+    const double tmax = sizeof(T) == 4 ? 3.4028234663852886e38 : 1.7976931348623157e308;  // (stay inside T's range)
+    out.node_cull_lo = (T)std::fmax(cull_lo, -tmax); out.node_cull_hi = (T)std::fmin(cull_hi, tmax);
     out.n_bvh = (uint32_t)h.fast_lite.size();
     out.n_bvh_lds = 0;
     out.bvh_lds = nullptr;

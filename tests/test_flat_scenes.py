@@ -106,6 +106,24 @@ def test_odd_lights_scene_sim_equals_oracle(sim, seed):
     assert np.allclose(s1, oc.sample_pixel(24, 18, 11, 7, 0, 24), rtol=RAD_RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("seed,shutter", ((3, (-0.7, 2.3)), (8, (0.25, 0.5)), (17, (1.5, 4.0)), (21, (-3.0, -1.0))))
+def test_shutter_intervals_other_than_0_1(sim, seed, shutter):
+    # camera.rs:63 draws the ray time from [t1, t2); moving spheres extrapolate outside their own (0, 1) (objects.rs:154-158) and
+    # the device's leaf boxes must cover the whole shutter interval (rt_pack.hpp: time hull)
+    fs = random_scene(seed)
+    fs.cam = tuple(fs.cam[:-2]) + (float(shutter[0]), float(shutter[1]))
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    for tm in (shutter[0], 0.5 * (shutter[0] + shutter[1]), shutter[1]):
+        ids, ts = sc.primary(40, 30, tm, 0.4, "f64")
+        oi, ot = oc.trace_primary(40, 30, tm, 0.4)
+        assert np.array_equal(ids, oi) and np.array_equal(ts, ot), (seed, tm)
+    got, casts = sc.render(20, 15, 0, 4)
+    ref, cnt = oc.render(20, 15, 0, 4, threads=4)
+    assert casts == cnt["casts"] and np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+
+
 def test_nan_scene_retries_and_drops(sim):
     # every diffuse bounce is NaN (flat_fuzz.nan_scene): floor samples are retried up to the cap, then dropped
     host = rt.FlatHostScene(nan_scene())

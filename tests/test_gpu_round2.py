@@ -428,3 +428,30 @@ def test_odd_lights_scene_gpu_equals_oracle(seed, gpu):
         assert int(st[2]) == cnt["nan_retries"] or abs(int(st[2]) - cnt["nan_retries"]) <= 0.02 * cnt["nan_retries"] + 2
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("seed,shutter", ((3, (-0.7, 2.3)), (17, (1.5, 4.0)), (21, (-3.0, -1.0))))
+def test_shutter_intervals_other_than_0_1_on_device(seed, shutter, gpu):
+    # ray times outside the (0, 1) the reference builds its BVH boxes for: moving spheres leave their boxes, the reference's loose
+    # per-axis box test (bvh.rs:26-58) still reaches some of them — the walk may not skip nodes on geometric grounds there
+    from flat_fuzz import random_scene
+    fs = random_scene(seed)
+    fs.cam = tuple(fs.cam[:-2]) + (float(shutter[0]), float(shutter[1]))
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        W, H = 56, 40
+        for tm in (shutter[0], 0.5 * (shutter[0] + shutter[1]), shutter[1]):
+            ids, ts = ds.trace_primary(W, H, tm, 0.4, "f64")
+            oi, ot = oc.trace_primary(W, H, tm, 0.4)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot), (seed, tm)
+        spp = 4
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
