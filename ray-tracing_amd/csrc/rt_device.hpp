@@ -120,6 +120,8 @@ template <class T> struct DScene {
     uint32_t n_perlins, n_perlin_lds;
     unsigned long long* tex_cache;    // -DRT_TEX_LDS_CACHE=<entries> builds: LDS texel cache of the render kernel (else unused)
     T time_lo, time_hi;             // ray times for which the leaf boxes of moving spheres are valid
+    T fast_lo, fast_hi;             // ray times for which walk_fast may run: time_lo..time_hi, or empty when the description's node boxes
+                                    // are not nested (rt_pack.hpp)
     T node_cull_lo, node_cull_hi;   // ray times at which every moving sphere lies inside all its ancestors' boxes in the REFERENCE's
                                     // trees (rt_pack.hpp); outside, walk_run may not skip a node on geometric grounds
     uint32_t n_world, n_lights, n_materials;
@@ -910,7 +912,7 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
     Walk<T> w;
     bool sure = false;
 #ifndef RT_NO_FAST_WALK
-    if (time >= sc.time_lo && time <= sc.time_hi) {  // (the device's trees are built from boxes valid for these ray times)
+    if (time >= sc.fast_lo && time <= sc.fast_hi) {  // (the device's trees are built from boxes valid for these ray times)
         walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, true);
         sure = walk_fast<T, F>(sc, w, o, d, inv, time);
     }

@@ -526,14 +526,34 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     // below the node classification's own margin): walk_run's geometric node culling is valid exactly there (rt_device.hpp:
     // walk_begin).  Boxes built by the reference for (0, 1) give [0, 1]; trees without moving spheres give every time.
     double cull_lo = -1.7976931348623157e308, cull_hi = 1.7976931348623157e308;
+    bool nested = true;
     {
         std::vector<int32_t> open;
         for (int32_t e = 0; e < (int32_t)h.bvh.size(); e++) {
             while (!open.empty() && h.bvh[open.back()].skip <= e) open.pop_back();
             const DBvhEntry<T>& en = h.bvh[e];
-            if (en.prim < 0) { open.push_back(e); continue; }
+            if (en.prim < 0) {
+                // walk_fast vouches a hit by the loose test of ONE reference node and lets the nesting of the boxes speak for the
+                // ancestors: a description whose child box is not inside its parent's (never the reference's own trees:
+                // surrounding_box, bvh.rs:11-25) gets no fast walk
+                if (!open.empty())
+                    for (int k = 0; k < 3; k++)
+                        if (!((double)en.mn[k] >= (double)h.bvh[open.back()].mn[k] && (double)en.mx[k] <= (double)h.bvh[open.back()].mx[k])) nested = false;
+                open.push_back(e);
+                continue;
+            }
             const RtPrim& p = d->prims[en.prim];
-            if (p.kind != RT_PRIM_MOVING_SPHERE) continue;
+            if (p.kind != RT_PRIM_MOVING_SPHERE) {  // a primitive that does not move must lie inside every ancestor box, at all times
+                double pmn[3], pmx[3];
+                prim_cull_box(p, 0.0, 1.0, pmn, pmx);
+                for (int32_t a : open)
+                    for (int k = 0; k < 3; k++) {
+                        const double mn = (double)h.bvh[a].mn[k], mx = (double)h.bvh[a].mx[k];
+                        const double slack = 1e-7 * (std::fabs(mn) + std::fabs(mx) + 1.0);
+                        if (!(pmn[k] >= mn - slack && pmx[k] <= mx + slack)) { cull_lo = 1.0; cull_hi = 0.0; }
+                    }
+                continue;
+            }
             const double r = std::fabs(p.d[8]), den = p.d[7] - p.d[6], t0 = p.d[6];
             for (int32_t a : open) {
                 for (int k = 0; k < 3; k++) {
@@ -557,6 +577,7 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     out.time_lo = (T)time_lo; out.time_hi = (T)time_hi;
     const double tmax = sizeof(T) == 4 ? 3.4028234663852886e38 : 1.7976931348623157e308;  // (stay inside T's range)
     out.node_cull_lo = (T)std::fmax(cull_lo, -tmax); out.node_cull_hi = (T)std::fmin(cull_hi, tmax);
+    out.fast_lo = nested ? out.time_lo : T(1); out.fast_hi = nested ? out.time_hi : T(0);
     out.n_bvh = (uint32_t)h.fast_lite.size();
     out.n_bvh_lds = 0;
     out.bvh_lds = nullptr;

@@ -78,6 +78,11 @@ extern "C" { unsigned long long g_sim_counters[8] = {0}; unsigned long long g_si
 extern "C" {
 const char* sim_last_error() { return rt::pack_error().c_str(); }
 uint32_t sim_scene_features(void* s) { return ((SimScene*)s)->features; }
+// the packer's ray-time intervals (f64 side): shutter hull, fast-walk interval, node-cull interval
+void sim_scene_intervals(void* s, double out[6]) {
+    const rt::DScene<double>& v = ((SimScene*)s)->s64.p.view;
+    out[0] = v.time_lo; out[1] = v.time_hi; out[2] = v.fast_lo; out[3] = v.fast_hi; out[4] = v.node_cull_lo; out[5] = v.node_cull_hi;
+}
 // force_generic != 0: always run the F_ALL instantiation (checks that every variant agrees with it)
 void* sim_scene_create(const RtSceneDesc* d, int* rc_out) {
     int rc = rt::validate(d);

@@ -124,6 +124,49 @@ def test_shutter_intervals_other_than_0_1(sim, seed, shutter):
     assert casts == cnt["casts"] and np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_bvh_boxes_that_do_not_fit_their_contents(sim, seed):
+    # The boundary takes ANY node boxes.  The reference's walk follows the boxes it is given (bvh.rs:114-129), so boxes that are
+    # too small, shifted, or not nested change what it finds — and the device must find the same: its geometric node culling
+    # and the one-box vouching of walk_fast assume containment / nesting, which the packer now verifies (rt_pack.hpp).
+    import random as _random
+    rng = _random.Random(900 + seed)
+    fs = None
+    for s0 in range(seed * 5, seed * 5 + 40):
+        cand = random_scene(s0)
+        if len(cand.nodes) >= 3:
+            fs = cand
+            break
+    assert fs is not None
+    for _ in range(rng.randint(1, 3)):
+        nd = fs.nodes[rng.randrange(len(fs.nodes))]
+        box = nd[0]
+        mode = rng.randrange(4)
+        for k in range(3):
+            w = box[3 + k] - box[k]
+            if mode == 0:    # shrink towards the centre
+                box[k] += 0.3 * w; box[3 + k] -= 0.3 * w
+            elif mode == 1:  # shift
+                box[k] += 0.4 * w; box[3 + k] += 0.4 * w
+            elif mode == 2:  # grow beyond the parent
+                box[k] -= 2.0 * w; box[3 + k] += 2.0 * w
+            else:            # cut one side only
+                box[3 + k] -= 0.5 * w * (k == seed % 3)
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    W, H = 48, 36
+    for tm in (0.0, 0.55):
+        for generic in (False, True):
+            ids, ts = sc.primary(W, H, tm, 0.5, "f64", generic)
+            oi, ot = oc.trace_primary(W, H, tm, 0.5)
+            assert np.array_equal(ids, oi), (seed, tm, generic, int((ids != oi).sum()))
+            assert np.array_equal(ts, ot)
+    got, casts = sc.render(20, 15, 0, 4)
+    ref, cnt = oc.render(20, 15, 0, 4, threads=4)
+    assert casts == cnt["casts"] and np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+
+
 def test_nan_scene_retries_and_drops(sim):
     # every diffuse bounce is NaN (flat_fuzz.nan_scene): floor samples are retried up to the cap, then dropped
     host = rt.FlatHostScene(nan_scene())

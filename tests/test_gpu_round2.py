@@ -455,3 +455,43 @@ def test_shutter_intervals_other_than_0_1_on_device(seed, shutter, gpu):
         assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
+
+
+@pytest.mark.parametrize("seed", (0, 3, 5, 9, 12, 14))
+def test_bvh_boxes_that_do_not_fit_their_contents_on_device(seed, gpu):
+    # node boxes that are too small, shifted or not nested (tests/test_flat_scenes.py has the CPU twin and the reasons): the device
+    # follows the boxes it is given exactly as the reference's walk would
+    import random as _random
+    from flat_fuzz import random_scene
+    rng = _random.Random(900 + seed)
+    fs = next(c for c in (random_scene(s0) for s0 in range(seed * 5, seed * 5 + 40)) if len(c.nodes) >= 3)
+    for _ in range(rng.randint(1, 3)):
+        box = fs.nodes[rng.randrange(len(fs.nodes))][0]
+        mode = rng.randrange(4)
+        for k in range(3):
+            w = box[3 + k] - box[k]
+            if mode == 0:
+                box[k] += 0.3 * w; box[3 + k] -= 0.3 * w
+            elif mode == 1:
+                box[k] += 0.4 * w; box[3 + k] += 0.4 * w
+            elif mode == 2:
+                box[k] -= 2.0 * w; box[3 + k] += 2.0 * w
+            else:
+                box[3 + k] -= 0.5 * w * (k == seed % 3)
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        W, H = 64, 48
+        for tm in (0.0, 0.55):
+            ids, ts = ds.trace_primary(W, H, tm, 0.5, "f64")
+            oi, ot = oc.trace_primary(W, H, tm, 0.5)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot), (seed, tm)
+        ref, cnt = oc.render(W, H, 0, 4, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, 4, precision="f64", stats=st)
+        close = (np.abs(acc.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()

@@ -169,6 +169,22 @@ def test_sim_depth_limits(sim):
     assert set(np.unique(a).tolist()) <= {0.0, 15.0, 30.0, 45.0, 60.0}
 
 
+def test_packer_intervals_of_the_named_scenes(sim):
+    # rt_pack.hpp: the reference's own trees are nested and contain their primitives, so every named scene keeps the fast walk over
+    # its whole shutter hull, and geometric node culling for (at least) the (0, 1) its boxes were built for
+    sim.sim_scene_intervals.argtypes = [C.c_void_p, C.c_void_p]
+    for name in rt.SCENES:
+        sc = SimScene(sim, name)
+        v = np.zeros(6)
+        sim.sim_scene_intervals(sc.h, v.ctypes.data)
+        assert (v[0], v[1]) == (0.0, 1.0) and (v[2], v[3]) == (0.0, 1.0), (name, v)
+        assert v[4] <= 0.0 and v[5] >= 1.0, (name, v)
+        if name == "random_scene":  # the only named scene with moving spheres INSIDE a BVH: its boxes hold them for (0, 1) and no longer
+            assert -0.01 < v[4] and v[5] < 1.01, (name, v)
+        else:
+            assert v[4] < -1e300 and v[5] > 1e300, (name, v)
+
+
 def test_sim_nan_retry_cap(sim):
     # ray_tracing.rs:102-110 retries a NaN sample for ever; this build gives up after max_nan_retries and takes the sample as
     # zero (stats[3]).  final_scene produces NaN samples, and with a cap of 1 some samples NaN twice in a row: same frames,
