@@ -236,3 +236,66 @@ def odd_lights_scene(seed):
     fs.background = [0.05, 0.05, 0.1]
     fs.camera([U(8, 12), U(3, 6), U(8, 12)], [0, 1.0, 0], [0, 1, 0], 40.0, 1.0, 0.0, 12.0, 0.0, 1.0)
     return fs
+
+
+def far_scene(seed, offset=(1.0e6, -3.0e5, 2.0e6)):
+    """Everything far from the origin (coordinates ~1e6 with features of size ~1): the f32 copies of the boxes resolve 0.06 - 0.25
+    there and the f32 node classification's margins are units wide, so almost every decision goes to the second (f64) level, the
+    exact test or the reference-order walk.  Spheres (some moving), cuboids and rectangles in a BVH, a floor, a light."""
+    rng = random.Random(11000 + seed)
+    U = rng.uniform
+    ox, oy, oz = offset
+    fs = F.FlatScene()
+    grey = fs.material(F.LAMBERTIAN, fs.solid(0.6, 0.6, 0.6))
+    lamp = fs.material(F.DIFFUSE_LIGHT, fs.solid(5.0, 5.0, 5.0))
+    glass = fs.material(F.DIELECTRIC, ref_idx=1.5)
+    metal = fs.material(F.METAL, albedo=(0.8, 0.8, 0.7), fuzz=0.05)
+    fs.add_world(fs.rect(1, ox - 30, ox + 30, oz - 30, oz + 30, oy - 1.0, 1.0, grey))
+    lr = fs.rect(1, ox - 2, ox + 2, oz - 2, oz + 2, oy + 8.0, -1.0, lamp)
+    fs.add_world(lr)
+    if seed % 2:
+        fs.add_light(lr)
+    ids = []
+    for _ in range(rng.randrange(6, 40)):
+        c = [ox + U(-6, 6), oy + U(0, 4), oz + U(-6, 6)]
+        k = rng.random()
+        if k < 0.5:
+            ids.append(fs.sphere(c, U(0.3, 1.2), rng.choice([grey, glass, metal])))
+        elif k < 0.7:
+            ids.append(fs.moving_sphere(c, [c[0] + U(-1, 1), c[1] + U(0, 0.5), c[2] + U(-1, 1)], 0.0, 1.0, U(0.3, 0.9), grey))
+        elif k < 0.9:
+            ids.append(fs.cuboid([c[0] - 0.5, c[1] - 0.5, c[2] - 0.5], [c[0] + U(0.3, 1), c[1] + U(0.3, 1), c[2] + U(0.3, 1)], grey))
+        else:
+            ids.append(fs.rect(rng.randrange(3), c[0] - 1, c[0] + 1, c[1] - 1, c[1] + 1, c[2], 1.0, grey))
+    fs.add_world(fs.build_bvh(ids, rng), bvh=True)
+    fs.add_world(fs.sphere([ox + U(-3, 3), oy + 1.0, oz + U(-3, 3)], 1.0, glass))
+    fs.background = [0.4, 0.5, 0.7]
+    fs.camera([ox + U(9, 13), oy + U(2, 6), oz + U(9, 13)], [ox, oy + 1.0, oz], [0, 1, 0], U(30, 45), 1.0, rng.choice([0.0, 0.1]), 14.0, 0.0, 1.0)
+    return fs
+
+
+def pile_scene(seed):
+    """Many primitives in the SAME place inside one BVH: copies of one sphere, of one cuboid and of one rectangle (different
+    materials), plus concentric spheres.  Every centroid coincides (the device's tree builder cannot split by position) and nearly
+    every hit is an exact tie, which the reference resolves by its visiting order."""
+    rng = random.Random(13000 + seed)
+    fs = F.FlatScene()
+    mats = [fs.material(F.LAMBERTIAN, fs.solid(rng.random(), rng.random(), rng.random())) for _ in range(6)]
+    mats.append(fs.material(F.METAL, albedo=(0.9, 0.8, 0.7), fuzz=0.0))
+    mats.append(fs.material(F.DIELECTRIC, ref_idx=1.5))
+    fs.add_world(fs.rect(1, -20, 20, -20, 20, -1.0, 1.0, mats[0]))
+    ids = []
+    n = 20 + 15 * (seed % 4)
+    for i in range(n):
+        ids.append(fs.sphere([0.0, 1.0, 0.0], 1.0, rng.choice(mats)))
+    for i in range(n // 2):
+        ids.append(fs.cuboid([2.0, -1.0, -1.0], [3.5, 1.0, 1.0], rng.choice(mats)))
+    for i in range(n // 3):
+        ids.append(fs.rect(0, -4.0, -2.0, -1.0, 2.0, 0.5, 1.0, rng.choice(mats)))
+    for i in range(8):
+        ids.append(fs.sphere([0.0, 1.0, 3.0], 0.2 + 0.1 * i, rng.choice(mats)))
+    rng.shuffle(ids)
+    fs.add_world(fs.build_bvh(ids, rng), bvh=True)
+    fs.background = [0.6, 0.7, 0.9]
+    fs.camera([7.0, 3.0, 9.0], [0.5, 0.5, 0.5], [0, 1, 0], 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return fs

@@ -495,3 +495,39 @@ def test_bvh_boxes_that_do_not_fit_their_contents_on_device(seed, gpu):
         assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
+
+
+def _gpu_same_as_oracle(fs, W=56, H=40, spp=4, times=((0.0, 0.5), (0.6, 0.1))):
+    host = rt.FlatHostScene(fs)
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        for tm, xi in times:
+            ids, ts = ds.trace_primary(W, H, tm, xi, "f64")
+            oi, ot = oc.trace_primary(W, H, tm, xi)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot), tm
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        got = acc.cpu().numpy()
+        close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
+
+
+@pytest.mark.parametrize("seed", (0, 1, 3, 6))
+def test_far_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: far_scene — coordinates ~1e6 (and 4e9), features ~1: the f32 node classification decides almost nothing
+    from flat_fuzz import far_scene
+    _gpu_same_as_oracle(far_scene(seed))
+    if seed == 0:
+        _gpu_same_as_oracle(far_scene(seed, offset=(-4.0e9, 1.0e9, 3.0e9)), times=((0.3, 0.5),))
+
+
+@pytest.mark.parametrize("seed", (0, 3))
+def test_pile_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: pile_scene — dozens of primitives in the same place inside one BVH (coinciding centroids, exact ties)
+    from flat_fuzz import pile_scene
+    _gpu_same_as_oracle(pile_scene(seed), W=41, H=31, times=((0.0, 0.5),))
