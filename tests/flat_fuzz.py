@@ -299,3 +299,75 @@ def pile_scene(seed):
     fs.background = [0.6, 0.7, 0.9]
     fs.camera([7.0, 3.0, 9.0], [0.5, 0.5, 0.5], [0, 1, 0], 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
     return fs
+
+
+def texture_scene(seed):
+    """NoiseTexture and ImageTexture in every position the flat form allows: Perlin tables with scales from tiny to huge (and
+    negative), images of awkward sizes (1x1, 3x2, 17x5, 64x33) on spheres, moving spheres, rectangles and cuboids, as emitters, as
+    the phase texture of a medium, and as the branches of nested checker textures; several tables and images per scene."""
+    rng = random.Random(17000 + seed)
+    U = rng.uniform
+    fs = F.FlatScene()
+    for _ in range(1 + seed % 3):  # Perlin tables: permutations + unit vectors (texture.rs:100-130)
+        perms = []
+        for _k in range(3):
+            p = list(range(256)); rng.shuffle(p); perms.append(p)
+        vecs = []
+        for _k in range(256):
+            v = [U(-1, 1), U(-1, 1), U(-1, 1)]
+            n = math.sqrt(sum(c * c for c in v)) or 1.0
+            vecs.append([c / n for c in v])
+        fs.perlins.append((perms[0], perms[1], perms[2], vecs))
+    for (w, h) in ((1, 1), (3, 2), (17, 5), (64, 33))[: 2 + seed % 3]:
+        fs.images.append((w, h, bytes(rng.randrange(256) for _ in range(w * h * 3))))
+
+    def noise():
+        return fs.texture(F.NOISE, table=rng.randrange(len(fs.perlins)), scale=rng.choice([0.1, 1.0, 4.0, 37.5, -2.0, 1e-3, 250.0]))
+
+    def image():
+        return fs.texture(F.IMAGE, table=rng.randrange(len(fs.images)))
+
+    def tex(depth=0):
+        c = rng.random()
+        if c < 0.35:
+            return noise()
+        if c < 0.7:
+            return image()
+        if c < 0.8 or depth >= 2:
+            return fs.solid(U(0.1, 0.9), U(0.1, 0.9), U(0.1, 0.9))
+        return fs.texture(rng.choice([F.CHECKER_3D, F.CHECKER_UV]), odd=tex(depth + 1), even=tex(depth + 1))
+
+    def mat():
+        c = rng.random()
+        if c < 0.7:
+            return fs.material(F.LAMBERTIAN, texture=tex())
+        if c < 0.85:
+            return fs.material(F.DIFFUSE_LIGHT, texture=tex())
+        return fs.material(F.METAL, albedo=(0.8, 0.8, 0.8), fuzz=0.1)
+
+    fs.add_world(fs.rect(1, -20, 20, -20, 20, -1.0, 1.0, fs.material(F.LAMBERTIAN, texture=tex())))
+    for _ in range(rng.randrange(5, 10)):
+        p = [U(-5, 5), U(0, 3), U(-5, 5)]
+        k = rng.random()
+        if k < 0.35:
+            prim = fs.sphere(p, U(0.5, 1.5), mat())
+        elif k < 0.5:
+            prim = fs.moving_sphere(p, [p[0] + U(-0.5, 0.5), p[1] + U(0, 0.6), p[2]], 0.0, 1.0, U(0.4, 1.0), mat())
+        elif k < 0.75:
+            prim = fs.rect(rng.randrange(3), p[0] - 1.5, p[0] + 1.5, p[1] - 1.0, p[1] + 2.0, p[2], rng.choice([-1.0, 1.0]), mat())
+        else:
+            prim = fs.cuboid(p, [p[0] + U(0.5, 2), p[1] + U(0.5, 2), p[2] + U(0.5, 2)], mat())
+        c = rng.random()
+        chain = () if c < 0.5 else ((("t", (U(-1, 1), 0.0, U(-1, 1))),) if c < 0.75 else (("t", (U(-1, 1), 0.0, U(-1, 1))), ("r", U(-40, 40))))
+        fs.add_world(prim, chain=chain)
+    ids = [fs.sphere([U(-5, 5), U(3, 5), U(-5, 5)], U(0.3, 0.8), mat()) for _ in range(rng.randrange(2, 10))]
+    fs.add_world(fs.build_bvh(ids, rng), bvh=True)
+    iso = fs.material(F.ISOTROPIC, texture=tex())
+    fs.add_world(fs.sphere([U(-3, 3), 1.5, U(-3, 3)], 1.8, fs.material(F.DIELECTRIC, ref_idx=1.5)), medium=(U(0.2, 1.0), iso))
+    lr = fs.rect(1, -2, 2, -2, 2, 8.0, -1.0, fs.material(F.DIFFUSE_LIGHT, texture=fs.solid(5, 5, 5)))
+    fs.add_world(lr)
+    if seed % 2:
+        fs.add_light(lr)
+    fs.background = [0.5, 0.6, 0.8]
+    fs.camera([U(9, 13), U(2, 6), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, 0.0, 14.0, 0.0, 1.0)
+    return fs

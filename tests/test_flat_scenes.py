@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import far_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, tie_scene
+from flat_fuzz import far_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -191,6 +191,29 @@ def test_far_scene_sim_equals_oracle(sim, seed):
     _same_as_oracle(sim, far_scene(seed))
     if seed in (0, 2):  # (no light list in the even seeds: a 4-unit light at 4e9 is an empty range in f32 and is refused at creation)
         _same_as_oracle(sim, far_scene(seed, offset=(-4.0e9, 1.0e9, 3.0e9)), times=((0.3, 0.5),))
+
+
+@pytest.mark.parametrize("seed", (0, 1, 3, 4, 5, 8, 9, 10))
+def test_moving_spheres_with_other_time_bases(sim, seed):
+    # MovingSphere(center1, center2, t1, t2): the times need not be (0, 1) (objects.rs:154-158 interpolates with any), and the node
+    # boxes of a description need not have been computed for the interval the camera uses — here the spheres' time bases are changed
+    # AFTER the tree's boxes were computed, so the boxes hold them at some ray times, or at none
+    fs = random_scene(seed)
+    n = 0
+    for i, (kind, m, d) in enumerate(fs.prims):
+        if kind == 1:
+            d = list(d)
+            d[6], d[7] = ((-1.0, 3.0), (0.5, 0.75), (2.0, 1.0))[n % 3]
+            fs.prims[i] = (kind, m, d)
+            n += 1
+    assert n > 0
+    _same_as_oracle(sim, fs, times=((0.0, 0.5), (0.5, 0.3), (1.0, 0.7)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_texture_scene_sim_equals_oracle(sim, seed):
+    # noise and image textures everywhere the flat form allows them (tests/flat_fuzz.py: texture_scene)
+    _same_as_oracle(sim, texture_scene(seed), times=((0.0, 0.5),), frame=(24, 18, 6))
 
 
 @pytest.mark.parametrize("seed", range(4))

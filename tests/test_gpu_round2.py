@@ -531,3 +531,26 @@ def test_pile_scene_gpu_equals_oracle(seed, gpu):
     # tests/flat_fuzz.py: pile_scene — dozens of primitives in the same place inside one BVH (coinciding centroids, exact ties)
     from flat_fuzz import pile_scene
     _gpu_same_as_oracle(pile_scene(seed), W=41, H=31, times=((0.0, 0.5),))
+
+
+@pytest.mark.parametrize("seed", (0, 1, 2, 5, 8))
+def test_texture_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: texture_scene — noise (1-3 Perlin tables, scales 1e-3 .. 250 and negative) and image textures (1x1 .. 64x33)
+    # on every primitive kind, as emitters, as a medium's phase texture and inside nested checkers
+    from flat_fuzz import texture_scene
+    _gpu_same_as_oracle(texture_scene(seed), times=((0.0, 0.5),), spp=6)
+
+
+@pytest.mark.parametrize("seed", (0, 3, 5, 9))
+def test_moving_spheres_with_other_time_bases_on_device(seed, gpu):
+    from flat_fuzz import random_scene
+    fs = random_scene(seed)
+    n = 0
+    for i, (kind, m, d) in enumerate(fs.prims):
+        if kind == 1:
+            d = list(d)
+            d[6], d[7] = ((-1.0, 3.0), (0.5, 0.75), (2.0, 1.0))[n % 3]
+            fs.prims[i] = (kind, m, d)
+            n += 1
+    assert n > 0
+    _gpu_same_as_oracle(fs, times=((0.0, 0.5), (0.5, 0.3), (1.0, 0.7)))
