@@ -371,3 +371,66 @@ def texture_scene(seed):
     fs.background = [0.5, 0.6, 0.8]
     fs.camera([U(9, 13), U(2, 6), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, 0.0, 14.0, 0.0, 1.0)
     return fs
+
+
+def extreme_scene(seed):
+    """Parameters at and beyond the edge of what the reference's scenes use: negative and zero sphere radii (the hollow-glass trick
+    of the book uses a negative one), zero-area and inverted rectangles, flat and inverted cuboids, Metal fuzz 0 / 1 / 3, Dielectric
+    ref_idx 1, 0.5, 0, -1.5, 2.4, FrostedDielectric fuzz 2, emitters with negative and huge power, albedos above 1, a medium of
+    density 1e-6 and one of 1e6 — mostly NaN / inf territory, which has to flow through the device exactly as through the oracle."""
+    rng = random.Random(19000 + seed)
+    U = rng.uniform
+    fs = F.FlatScene()
+
+    def mat():
+        c = rng.randrange(9)
+        if c == 0:
+            return fs.material(F.METAL, albedo=(U(0.5, 1.5), U(0.5, 1.5), U(0.5, 1.5)), fuzz=rng.choice([0.0, 1.0, 3.0]))
+        if c == 1:
+            return fs.material(F.DIELECTRIC, ref_idx=rng.choice([1.0, 0.5, 0.0, -1.5, 2.4, 1e-9, 1e9]))
+        if c == 2:
+            return fs.material(F.FROSTED, ref_idx=rng.choice([1.5, 0.7]), fuzz=rng.choice([0.0, 2.0]))
+        if c == 3:
+            return fs.material(F.DIFFUSE_LIGHT, texture=fs.solid(*rng.choice([(-3.0, 2.0, 1.0), (1e30, 1e30, 1e30), (0.0, 0.0, 0.0), (4.0, 4.0, 4.0)])))
+        return fs.material(F.LAMBERTIAN, texture=fs.solid(U(0.0, 1.6), U(0.0, 1.6), U(0.0, 1.6)))
+
+    fs.add_world(fs.rect(1, -20, 20, -20, 20, -1.0, 1.0, fs.material(F.LAMBERTIAN, texture=fs.solid(0.7, 0.7, 0.7))))
+    ids = []
+    for _ in range(rng.randrange(8, 16)):
+        p = [U(-5, 5), U(0, 3), U(-5, 5)]
+        k = rng.randrange(8)
+        if k == 0:
+            prim = fs.sphere(p, rng.choice([-0.8, 0.0, 1e-12, 1.0]), mat())
+        elif k == 1:   # hollow sphere: outer positive, inner negative radius, same centre
+            fs.add_world(fs.sphere(p, 1.0, fs.material(F.DIELECTRIC, ref_idx=1.5)))
+            prim = fs.sphere(p, -0.9, fs.material(F.DIELECTRIC, ref_idx=1.5))
+        elif k == 2:
+            prim = fs.moving_sphere(p, p, 0.0, 1.0, rng.choice([-0.5, 0.7]), mat())   # "moving" without motion
+        elif k == 3:
+            prim = fs.rect(rng.randrange(3), p[0], p[0], p[1] - 1, p[1] + 1, p[2], 1.0, mat())        # zero width
+        elif k == 4:
+            prim = fs.rect(rng.randrange(3), p[0] + 1, p[0] - 1, p[1] - 1, p[1] + 1, p[2], -1.0, mat())  # inverted range
+        elif k == 5:
+            prim = fs.cuboid(p, [p[0] + 1.0, p[1], p[2] + 1.0], mat())                                  # flat
+        elif k == 6:
+            prim = fs.cuboid([p[0] + 1, p[1] + 1, p[2] + 1], p, mat())                                  # min > max
+        else:
+            prim = fs.sphere(p, U(0.4, 1.2), mat())
+        if rng.random() < 0.5:
+            ids.append(prim)
+        else:
+            fs.add_world(prim, chain=() if rng.random() < 0.6 else (("t", (U(-1, 1), 0.0, U(-1, 1))), ("r", U(-50, 50))))
+    while len(ids) < 2:
+        ids.append(fs.sphere([U(-5, 5), 4.0, U(-5, 5)], 0.5, mat()))
+    fs.add_world(fs.build_bvh(ids, rng), bvh=True)
+    iso = fs.material(F.ISOTROPIC, texture=fs.solid(1.3, 0.9, 0.2))
+    fs.add_world(fs.sphere([U(-3, 3), 1.0, U(-3, 3)], 1.5, fs.material(F.DIELECTRIC, ref_idx=1.5)), medium=(rng.choice([1e-6, 1e6, 0.5]), iso))
+    lr = fs.rect(1, -2, 2, -2, 2, 8.0, -1.0, fs.material(F.DIFFUSE_LIGHT, texture=fs.solid(5, 5, 5)))
+    fs.add_world(lr)
+    if seed % 2:
+        fs.add_light(lr)
+        gs = fs.sphere([U(-2, 2), 1.0, U(-2, 2)], rng.choice([1.0, -1.0, 0.0]), fs.material(F.DIELECTRIC, ref_idx=1.5))
+        fs.add_world(gs); fs.add_light(gs)
+    fs.background = [0.5, 0.6, 0.8]
+    fs.camera([U(9, 13), U(2, 6), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, rng.choice([0.0, 0.3]), 14.0, 0.0, 1.0)
+    return fs

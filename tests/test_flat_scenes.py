@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import far_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
+from flat_fuzz import extreme_scene, far_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -214,6 +214,12 @@ def test_moving_spheres_with_other_time_bases(sim, seed):
 def test_texture_scene_sim_equals_oracle(sim, seed):
     # noise and image textures everywhere the flat form allows them (tests/flat_fuzz.py: texture_scene)
     _same_as_oracle(sim, texture_scene(seed), times=((0.0, 0.5),), frame=(24, 18, 6))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_extreme_scene_sim_equals_oracle(sim, seed):
+    # degenerate primitives and out-of-range material parameters (tests/flat_fuzz.py: extreme_scene): NaN / inf must flow alike
+    _same_as_oracle(sim, extreme_scene(seed), frame=(24, 18, 6))
 
 
 @pytest.mark.parametrize("seed", range(4))

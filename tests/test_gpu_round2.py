@@ -554,3 +554,11 @@ def test_moving_spheres_with_other_time_bases_on_device(seed, gpu):
             n += 1
     assert n > 0
     _gpu_same_as_oracle(fs, times=((0.0, 0.5), (0.5, 0.3), (1.0, 0.7)))
+
+
+@pytest.mark.parametrize("seed", (0, 1, 3, 4, 7, 10, 13))
+def test_extreme_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: extreme_scene — negative / zero radii, degenerate rectangles and cuboids, material parameters far outside the
+    # reference's scenes: NaN / inf have to flow through the device as through the oracle (and NaN samples are retried alike)
+    from flat_fuzz import extreme_scene
+    _gpu_same_as_oracle(extreme_scene(seed), spp=6)
