@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak test on the GPU: randomly generated flat scenes (tests/flat_fuzz.py) through the C-ABI against the oracle
 rebuilt from the same description — probe ids/t bit-exact, frames sample-for-sample.  Not part of the test suite
-(the suite runs seeds 0..11); run by hand:  python tools/gpu_fuzz.py FIRST LAST"""
+(the suite runs seeds 0..11); run by hand:  python tools/gpu_fuzz.py FIRST LAST [generator]
+generator: a scene generator of tests/flat_fuzz.py (random_scene, tie_scene, medium_scene, texture_scene, extreme_scene, far_scene,
+pile_scene, odd_lights_scene); default random_scene."""
 import os
 import sys
 
@@ -12,10 +14,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import ray_tracing_amd as rt  # noqa: E402
-from flat_fuzz import random_scene  # noqa: E402
+import flat_fuzz  # noqa: E402
 from oracle_lib import OracleScene  # noqa: E402
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
+random_scene = getattr(flat_fuzz, sys.argv[3] if len(sys.argv) > 3 else "random_scene")
 rt.init(0)
 bad = 0
 for seed in range(first, last):
