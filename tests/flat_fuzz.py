@@ -434,3 +434,50 @@ def extreme_scene(seed):
     fs.background = [0.5, 0.6, 0.8]
     fs.camera([U(9, 13), U(2, 6), U(9, 13)], [0, 1.0, 0], [0, 1, 0], U(30, 45), 1.0, rng.choice([0.0, 0.3]), 14.0, 0.0, 1.0)
     return fs
+
+
+def instancing_scene(seed):
+    """One BVH referenced by several instances (as it is, behind Translate + RotateY, and as the boundary of a ConstantMedium), a second
+    BVH used twice with different chains, and rectangle / cuboid lights behind rotating wrapper chains (the light list repeats the
+    world's chain, as the reference's scenes do for their glass sphere)."""
+    rng = random.Random(23000 + seed)
+    U = rng.uniform
+    fs = F.FlatScene()
+    grey = fs.material(F.LAMBERTIAN, fs.solid(0.6, 0.6, 0.6))
+    red = fs.material(F.LAMBERTIAN, fs.solid(0.7, 0.2, 0.2))
+    glass = fs.material(F.DIELECTRIC, ref_idx=1.5)
+    metal = fs.material(F.METAL, albedo=(0.8, 0.8, 0.7), fuzz=0.2)
+    lamp = fs.material(F.DIFFUSE_LIGHT, fs.solid(6.0, 6.0, 6.0))
+    iso = fs.material(F.ISOTROPIC, texture=fs.solid(0.8, 0.8, 0.9))
+    fs.add_world(fs.rect(1, -25, 25, -25, 25, -1.0, 1.0, grey))
+
+    def cluster(n):
+        ids = []
+        for _ in range(n):
+            c = [U(-1.5, 1.5), U(0, 2), U(-1.5, 1.5)]
+            k = rng.random()
+            if k < 0.5:
+                ids.append(fs.sphere(c, U(0.3, 0.7), rng.choice([grey, red, glass, metal])))
+            elif k < 0.7:
+                ids.append(fs.moving_sphere(c, [c[0] + U(-0.4, 0.4), c[1] + U(0, 0.4), c[2]], 0.0, 1.0, U(0.3, 0.6), red))
+            else:
+                ids.append(fs.cuboid([c[0] - 0.4, c[1] - 0.4, c[2] - 0.4], [c[0] + U(0.2, 0.6), c[1] + U(0.2, 0.6), c[2] + U(0.2, 0.6)], grey))
+        return fs.build_bvh(ids, rng)
+
+    a = cluster(rng.randrange(3, 12))
+    fs.add_world(a, bvh=True)
+    fs.add_world(a, bvh=True, chain=(("t", (U(4, 6), 0.0, U(-2, 2))), ("r", U(-60, 60))))
+    fs.add_world(a, bvh=True, chain=(("t", (U(-6, -4), 0.5, U(-2, 2))),), medium=(U(0.3, 1.5), iso))
+    b = cluster(rng.randrange(2, 6))
+    fs.add_world(b, bvh=True, chain=(("r", U(-30, 30)), ("t", (0.0, 0.0, U(4, 6)))))
+    fs.add_world(b, bvh=True, chain=(("t", (U(-2, 2), 2.5, U(-6, -4))), ("r", 90.0)))
+    lch = (("t", (U(-2, 2), 7.0, U(-2, 2))), ("r", U(-45, 45)))
+    lr = fs.rect(1, -1.5, 1.5, -1.0, 1.0, 0.0, -1.0, lamp)
+    fs.add_world(lr, chain=lch); fs.add_light(lr, chain=lch)
+    if seed % 2:
+        cch = (("r", U(-80, 80)), ("t", (U(5, 7), 0.0, U(5, 7))))
+        cb = fs.cuboid([-0.5, 0.0, -0.5], [0.5, 1.5, 0.7], lamp)
+        fs.add_world(cb, chain=cch); fs.add_light(cb, chain=cch)
+    fs.background = [0.1, 0.15, 0.25]
+    fs.camera([U(10, 14), U(3, 7), U(10, 14)], [0, 1.0, 0], [0, 1, 0], U(35, 50), 1.0, 0.0, 15.0, 0.0, 1.0)
+    return fs

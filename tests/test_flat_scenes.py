@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import extreme_scene, far_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
+from flat_fuzz import extreme_scene, far_scene, instancing_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -220,6 +220,12 @@ def test_texture_scene_sim_equals_oracle(sim, seed):
 def test_extreme_scene_sim_equals_oracle(sim, seed):
     # degenerate primitives and out-of-range material parameters (tests/flat_fuzz.py: extreme_scene): NaN / inf must flow alike
     _same_as_oracle(sim, extreme_scene(seed), frame=(24, 18, 6))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_instancing_scene_sim_equals_oracle(sim, seed):
+    # one tree behind several instances (plain, transformed, as a medium's boundary); rotated rectangle / cuboid lights
+    _same_as_oracle(sim, instancing_scene(seed), frame=(24, 18, 6))
 
 
 @pytest.mark.parametrize("seed", range(4))

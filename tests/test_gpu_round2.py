@@ -562,3 +562,11 @@ def test_extreme_scene_gpu_equals_oracle(seed, gpu):
     # reference's scenes: NaN / inf have to flow through the device as through the oracle (and NaN samples are retried alike)
     from flat_fuzz import extreme_scene
     _gpu_same_as_oracle(extreme_scene(seed), spp=6)
+
+
+@pytest.mark.parametrize("seed", (0, 1, 4, 7))
+def test_instancing_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: instancing_scene — one BVH behind several instances (plain, Translate + RotateY, as a medium's boundary),
+    # rectangle and cuboid lights behind rotating chains
+    from flat_fuzz import instancing_scene
+    _gpu_same_as_oracle(instancing_scene(seed), spp=6)
