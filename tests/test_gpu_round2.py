@@ -570,3 +570,21 @@ def test_instancing_scene_gpu_equals_oracle(seed, gpu):
     # rectangle and cuboid lights behind rotating chains
     from flat_fuzz import instancing_scene
     _gpu_same_as_oracle(instancing_scene(seed), spp=6)
+
+
+@pytest.mark.parametrize("name", ("cornell_box", "random_scene", "cornell_smoke"))
+@pytest.mark.parametrize("W,H,spp,s0", ((2, 2, 5, 0), (3, 700, 2, 7), (2051, 3, 2, 0), (500, 2, 3, 4294967000), (9, 17, 257, 1), (64, 64, 1, 123456)))
+def test_odd_frame_shapes_and_sample_ranges(name, W, H, spp, s0, scenes):
+    # the launch arithmetic (tiles, job lists, sample chunks, the grid's z dimension, atomics vs plain adds) at shapes far from the
+    # benchmark's: slivers, a frame smaller than one tile, sample indices next to 2^32, one sample, a prime number of samples
+    ds = scenes(name, W / H)
+    oc = OracleScene(name, W / H)
+    ref, cnt = oc.render(W, H, s0, spp, threads=8)
+    for no_sort in (False, True):
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, s0, spp, precision="f64", stats=st, no_sort=no_sort)
+        got = acc.cpu().numpy()
+        close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
+        assert close.mean() >= 0.995, (name, W, H, spp, no_sort, close.mean())
+        assert int(st[0]) == W * H * spp and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
