@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/rt_asan_validate
 mkdir -p "$OUT"
 H=$ROOT/ray-tracing_amd/host
-g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -ffp-contract=off -DRT_HOST_SIM -Wno-unknown-pragmas \
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=all -fno-omit-frame-pointer -ffp-contract=off -DRT_HOST_SIM -Wno-unknown-pragmas \
     -I"$ROOT/tests/hostsim" -I"$ROOT/ray-tracing_amd/csrc" -I"$ROOT/include" -I"$H" \
     "$ROOT/tools/asan_validate.cpp" "$ROOT/tests/hostsim/sim.cpp" "$H/scene_api.cpp" "$H/scenes.cpp" "$H/flatten.cpp" "$H/jpeg.cpp" "$H/capi.cpp" \
     -pthread -o "$OUT/asan_validate"
