@@ -203,7 +203,14 @@ void gpu_thread(Shared* sh, int g) {
 int main(int argc, char** argv) {
     const Options o = parse(argc, argv);
     const auto t0 = std::chrono::steady_clock::now();
-    RthScene* hs = rth_scene_build(o.scene.c_str(), (double)o.width / (double)o.height, o.seed, o.image.empty() ? nullptr : o.image.c_str());
+    std::string image = o.image;
+    if (image.empty()) {  // texture.rs:70 opens "images/earthmap.jpg" relative to the working directory; here: the raster shipped beside the program
+        std::error_code ec;
+        const std::filesystem::path exe = std::filesystem::read_symlink("/proc/self/exe", ec);
+        const std::filesystem::path beside = exe.parent_path() / "assets" / "earthmap.ppm";
+        if (!ec && std::filesystem::exists(beside, ec)) image = beside.string();
+    }
+    RthScene* hs = rth_scene_build(o.scene.c_str(), (double)o.width / (double)o.height, o.seed, image.empty() ? nullptr : image.c_str());
     if (!hs) die(std::string("scene: ") + rth_last_error());
     const double seconds_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Shared sh;

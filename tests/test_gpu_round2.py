@@ -355,7 +355,7 @@ def _png_pixels(path):
     return raw[:, 1:].reshape(h, w, 3)
 
 
-@pytest.mark.parametrize("name,W,H,spp", (("cornell_box", 72, 56, 12), ("random_scene", 61, 35, 5)))
+@pytest.mark.parametrize("name,W,H,spp", (("cornell_box", 72, 56, 12), ("random_scene", 61, 35, 5), ("earth", 40, 30, 4)))
 def test_native_launcher_equals_python_path(name, W, H, spp, scenes, tmp_path):
     # ray-tracing_amd/rt_render (host/rt_render_main.cpp): C++ against the two C headers only — no Python, no torch in that
     # process.  Same scene, seed and sample ranges -> the same 8-bit image as renderer.render + resolve + write_png.
