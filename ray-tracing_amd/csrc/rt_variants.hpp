@@ -21,7 +21,13 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 //    f64 3 waves 2026 against 1753 at 4 (and 1664 at 2); f32 stays at 4 (2970 against 2591 at 3).
 //    The generic f64 variant runs as fast at 2 waves as at 3 (final_scene 1024^2 @ 64 spp: 227 against 225 Msamples/s) with
 //    236 B of spills per lane instead of 576 B: at 3 waves the scratch of all resident waves (113 MB) does not fit the
-//    32 MB of L2 and 257 GB per launch went to HBM (profiles/r02_final_*); at 2 waves it fits.  f32 keeps 3 (370 against 272).
+//    32 MB of L2 and 257 GB per launch went to HBM; at 2 waves it fits.  f32 kept 3 (370 against 272).
+//    LATER IN ROUND 2, once the uniform scene reads were scalar loads again (rt_kernels.inc: the job counter as a restrict
+//    parameter: 46 fewer live vector registers' worth of records), the balance tipped: 3 waves with 1184 LDS entries measure
+//    278 against 239 Msamples/s (f64, final_scene 1024^2 @ 64 spp; 314 against 255 at 2048^2) and f32 at 4 waves with 896 entries
+//    418 against 375 — issue slots busy 74 % instead of 58 %.  The price is the spill traffic again: 524 B per lane, 196 GB per
+//    launch through the memory side (810 GB/s, a tenth of the HBM peak; profiles/r02_final_*).  Throughput decides: 3 / 4 waves.
+//    -DRT_WAVES_PER_SIMD=2 -DRT_LDS_BVH_ENTRIES=2048 builds the low-traffic form (0.45 GB per launch).
 //  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
 //    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
@@ -29,7 +35,7 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
     return RT_WAVES_PER_SIMD;
 #else
     if (F & F_BVH) {
-        if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? 2 : 3;  // the generic variant (final_scene)
+        if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? 3 : 4;  // the generic variant (final_scene)
         return sizeof(T) == 8 ? 3 : 4;                                                      // spheres + BVH (random_scene)
     }
     return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
@@ -39,8 +45,8 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_en
 #ifdef RT_LDS_BVH_ENTRIES
     return RT_LDS_BVH_ENTRIES;
 #else
-    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return 2048u;  // f64 generic: 2 blocks x (64 KB + 6.75 KB Perlin table + 6 KB)
-    return (sizeof(T) == 4 && (F & F_NOISE)) ? 1248u : 1024u;  // f32 generic: 3 blocks x (39 KB + 4.75 KB Perlin table + 6 KB)
+    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
+    return (sizeof(T) == 4 && (F & F_NOISE)) ? 896u : 1024u;  // f32 generic: 4 blocks x (28 KB + 4.75 KB Perlin table + 6 KB)
 #endif
 }
 // Perlin tables staged in LDS (scenes.rs uses one per NoiseTexture: two_perlin_spheres 2, final_scene 1)
