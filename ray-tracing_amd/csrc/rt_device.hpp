@@ -34,15 +34,15 @@ extern "C" unsigned long long g_sim_walk_hist[64];  // walks by number of node c
 #endif
 
 // Profiling build (-DRT_PHASE_CLOCK, tools/build_ab.py): per-wave cycle and active-lane sums per phase of the
-// wave-level render kernel, printed for a few blocks.  Slots: [i] cycles, [8+i] cycles x active lanes.
+// wave-level render kernel, printed for a few blocks.  Slots: [i] cycles, [16+i] cycles x active lanes.
 #if defined(RT_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
-__device__ inline unsigned long long* rt_pc() { __shared__ unsigned long long pc[4][16]; return pc[threadIdx.x >> 6]; }
+__device__ inline unsigned long long* rt_pc() { __shared__ unsigned long long pc[4][32]; return pc[threadIdx.x >> 6]; }
 #define RT_PCB() unsigned long long pc_t_ = __builtin_readcyclecounter()
 #define RT_PCE(i)                                                                                        \
     do {                                                                                                 \
         const unsigned long long n_ = __builtin_readcyclecounter(), m_ = __builtin_amdgcn_ballot_w64(true); \
         if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) {                                      \
-            rt_pc()[i] += n_ - pc_t_; rt_pc()[8 + (i)] += (n_ - pc_t_) * (unsigned long long)__builtin_popcountll(m_); \
+            rt_pc()[i] += n_ - pc_t_; rt_pc()[16 + (i)] += (n_ - pc_t_) * (unsigned long long)__builtin_popcountll(m_); \
         }                                                                                                \
         pc_t_ = __builtin_readcyclecounter();                                                            \
     } while (0)
@@ -892,8 +892,10 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
     w.closest = closest;
     if (sizeof(T) == 8 && w.any && !doubt) {
         RT_SIM_COUNT(7);
+        RT_PCB();
         const DBvhEntry<T>& pb = sc.bvh[ref_parent];
         if (!aabb_vouch(pb.mn, pb.mx, o, d, w.t_min, closest, closest < t_max0)) doubt = true;
+        RT_PCE(10);
     }
 #if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
     RT_SIM_WALK(sim_n0);
@@ -907,13 +909,18 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
                                 T t_min, T t_max, T& t_out, int& prim_out, int& side_out) {
     if (!has<F>(F_BVH) || geom_kind == 0) {
         prim_out = (int)geom_index;
-        return prim_hit<T, F>(sc.prims[geom_index], o, d, inv, time, t_min, t_max, t_out, side_out);
+        RT_PCB();
+        const bool h = prim_hit<T, F>(sc.prims[geom_index], o, d, inv, time, t_min, t_max, t_out, side_out);
+        RT_PCE(6);
+        return h;
     }
     Walk<T> w;
     bool sure = false;
 #ifndef RT_NO_FAST_WALK
     if (time >= sc.fast_lo && time <= sc.fast_hi) {  // (the device's trees are built from boxes valid for these ray times)
+        RT_PCB();
         walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, true);
+        RT_PCE(9);
         sure = walk_fast<T, F>(sc, w, o, d, inv, time);
     }
 #endif
@@ -922,8 +929,10 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
 #endif
     if (!sure) {
         RT_SIM_COUNT(6);
+        RT_PCB();
         walk_begin<T, F>(sc, geom_index, o, d, time, t_min, t_max, w, false);
         walk_run<T, F>(sc, w, o, d, inv, time);
+        RT_PCE(11);
     }
     if (w.any) { prim_out = w.prim; side_out = w.side; }
     t_out = w.closest;
@@ -1078,6 +1087,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
     for (uint32_t i = 0; i < sc.n_world; i++) {
         const DInstance<T>& in = sc.world[i];
         V3<T> o = ray.ori, d = ray.dir;
+        RT_PCB();
 #if defined(RT_SHARED_RECIP)
         // rectangle tests divide by a direction component: the reciprocal part of those divisions is shared per axis and,
         // where no RotateY intervenes, per ray (Recip)
@@ -1089,6 +1099,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
         xform_ray<T, F>(sc, in, o, d);
         const RayInv<T> inv(d);  // plain divisions: just the direction
 #endif
+        RT_PCE(8);
         const bool med = has<F>(F_MEDIUM) && in.is_medium;
         T ta = T(0);
         // what a medium does once both boundary distances are known (src/objects.rs:537-556)
@@ -1117,6 +1128,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             const int n = boundary_two<T, F>(sc.prims[in.geom_index], o, d, ray.time, ta, tb);
             if (n >= 0) {
                 if (n == 2) medium_event(tb);
+                RT_PCE(7);
                 continue;
             }
         }

@@ -230,7 +230,10 @@ __device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int ma
     Hit<T> h;
     MediumXi mxi{&rng, 0.0};
     const bool any = world_hit<T, F>(sc, st.ray, T(0.001), Lim<T>::max(), mxi, h);
-    return segment_post<T, F>(sc, st, any, h, rec, mat_index);
+    RT_PCB();
+    const int next = segment_post<T, F>(sc, st, any, h, rec, mat_index);
+    RT_PCE(12);
+    return next;
 }
 
 // Lambertian: src/materials.rs:36-50 + ray_tracing.rs:25-43 (emitted == 0)

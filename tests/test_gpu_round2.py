@@ -160,7 +160,8 @@ def test_earth_frame_from_jpeg_equals_frame_from_its_raster(gpu, golden_dir, tmp
         ds.render_into(acc, 0, spp, precision="f64")
         frames.append(acc.cpu().numpy())
         ds.close(); hs.close()
-    assert np.array_equal(frames[0], frames[1])  # same texels -> same frame, bit for bit
+    # same texels -> same frame, up to the order of the float additions of a launch that is cut into sample chunks
+    assert np.allclose(frames[0], frames[1], rtol=1e-6, atol=0)
     # and it is the oracle's frame for that raster (the texture is really sampled: the frame differs from the default asset's)
     ref, _ = OracleScene("earth", W / H, image_path=ppm).render(W, H, 0, spp, threads=8)
     assert (np.abs(frames[0] - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2).mean() >= 0.998
