@@ -307,8 +307,33 @@ __device__ inline bool path_segment(const DScene<T>& sc, PathState<T>& st, int m
 }
 
 // Fresh camera path for sample (u,v): src/ray_tracing.rs:103
+// The camera (24 numbers, 48 scalar registers in f64) is read where a path starts, from the kernel-argument segment (the scene is the
+// FIRST argument of every kernel), behind an opaque copy of its address: as a member of the by-value scene the compiler loaded it once
+// at kernel entry and carried it — in scalar registers and, beyond their number, in spill lanes of vector registers — through the
+// whole sample loop (render_kernel_sorted<f64, cornell>: 98 -> 66 spilled scalars... see DESIGN §4).
+template <class T> __device__ inline DCamera<T> scene_camera(const DScene<T>& sc, uint32_t varying) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_HOST_SIM) && !defined(RT_CAMERA_IN_REGISTERS)
+    typedef const __attribute__((address_space(4))) char* kernarg_bytes;
+    typedef const __attribute__((address_space(4))) DCamera<T>* kernarg_camera;
+    kernarg_bytes p = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(DScene<T>, cam);
+    // not a loop invariant the compiler may hoist: the address "depends" on a number that changes from path to path (a plain asm, not
+    // a volatile one, which would count as a write to memory and cost the kernel its scalar scene reads)
+    const int vary = __builtin_amdgcn_readfirstlane((int)varying);
+    asm("" : "+s"(p) : "s"(vary));
+    kernarg_camera c = (kernarg_camera)p;
+    DCamera<T> cam;
+    for (int k = 0; k < 3; k++) {
+        cam.origin[k] = c->origin[k]; cam.llc[k] = c->llc[k]; cam.horizontal[k] = c->horizontal[k]; cam.vertical[k] = c->vertical[k];
+        cam.u[k] = c->u[k]; cam.v[k] = c->v[k]; cam.w[k] = c->w[k];
+    }
+    cam.lens_radius = c->lens_radius; cam.t1 = c->t1; cam.t2 = c->t2;
+    return cam;
+#else
+    return sc.cam;
+#endif
+}
 template <class T> __device__ inline void start_path(const DScene<T>& sc, PathState<T>& st, T u, T v, Rng& rng) {
-    st.ray = get_ray(sc.cam, u, v, rng);
+    st.ray = get_ray(scene_camera(sc, rng.s0), u, v, rng);
     st.beta = V3<T>(T(1), T(1), T(1));
     st.L = V3<T>(T(0), T(0), T(0));
     st.seg = 0;
