@@ -65,14 +65,17 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin
 #define RT_SORT_BLOCK 256  // lanes per block of the sorted kernel (rt_kernels.inc)
 #endif
 template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds_bytes() {
-    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * RT_SORT_BLOCK * (uint32_t)sizeof(T) + 24u * RT_SORT_BLOCK + 192u * RT_SORT_TILE_H + 68u +
+    return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * RT_SORT_BLOCK * (uint32_t)sizeof(T) + 24u * RT_SORT_BLOCK + 384u * RT_SORT_TILE_H + 144u +
            lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
 }
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
 #ifdef RT_SORTED_MAX_WAVES
     constexpr uint32_t most = RT_SORTED_MAX_WAVES;
 #else
-    constexpr uint32_t most = sizeof(T) == 8 ? 4u : 7u;
+    // f64 with media (cornell_smoke): at 4 waves the persistent-block kernel spills 204 B per lane, 53 MB of scratch for the resident
+    // lanes, more than the L2 holds (29.8 GB per 31 ms launch went to the memory side); at 3 waves 24 B: +2 % (2255 -> 2298 Msamples/s
+    // at 1024 spp per launch, 2170 -> 2218 at 64).  Without media 3 waves lose 12 % (cornell_box: spills are 112 B there and fit).
+    constexpr uint32_t most = sizeof(T) == 8 ? ((F & F_MEDIUM) ? 3u : 4u) : 7u;
 #endif
     // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
     // blocks per CU that LDS admits x waves per block / 4 SIMDs
