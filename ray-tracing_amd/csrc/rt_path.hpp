@@ -240,9 +240,12 @@ __device__ inline int segment_cast(const DScene<T>& sc, PathState<T>& st, int ma
 template <class T, uint32_t F>
 __device__ inline void shade_lambert(const DScene<T>& sc, PathState<T>& st, const HitRecord<T>& rec, uint32_t mat_index, Rng& rng) {
     const DMaterial<T>& m = sc.materials[mat_index];
+    RT_PCB();
     V3<T> attenuation = texture_value<T, F>(sc, m.texture, rec.u, rec.v, rec.p);
+    RT_PCE(13);
     V3<T> dir; T pdf_value, scattering_pdf;
     lambertian_sample<T, F>(sc, rec, rng, dir, pdf_value, scattering_pdf);
+    RT_PCE(14);
     st.beta = elemul(st.beta, attenuation) * scattering_pdf / pdf_value;
     st.ray.dir = dir;
 }
