@@ -264,11 +264,12 @@ def test_persistent_kernel_sample_chunks(name, W, H, spp, scenes):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
 
 
-def test_concurrent_launches_on_two_streams(scenes):
+@pytest.mark.parametrize("name,W,H,spp", (("random_scene", 96, 64, 24), ("cornell_box", 320, 256, 6)))
+def test_concurrent_launches_on_two_streams(name, W, H, spp, scenes):
     # rt_render is asynchronous on the caller's stream; two launches of ONE scene handle in flight on different streams
-    # draw their jobs from different counters of the handle's ring and must not disturb each other
-    ds = scenes("random_scene", 1.5)
-    W, H, spp = 96, 64, 24
+    # draw their jobs from different counters of the handle's ring and must not disturb each other (random_scene: persistent
+    # waves; cornell_box: the block-sorted kernel's persistent blocks, more jobs than resident blocks)
+    ds = scenes(name, W / H)
     seq = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
     ds.render_into(seq[0], 0, spp, precision="f64")
     ds.render_into(seq[1], spp, spp, precision="f64")
