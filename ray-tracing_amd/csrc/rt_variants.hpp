@@ -28,6 +28,12 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 //    418 against 375 — issue slots busy 74 % instead of 58 %.  The price is the spill traffic again: 524 B per lane, 196 GB per
 //    launch through the memory side (810 GB/s, a tenth of the HBM peak; profiles/r02_final_*).  Throughput decides: 3 / 4 waves.
 //    -DRT_WAVES_PER_SIMD=2 -DRT_LDS_BVH_ENTRIES=2048 builds the low-traffic form (0.45 GB per launch).
+//    END OF ROUND 2 (scalar scene reads, streaming jobs, camera read at path start), measured again: spheres + BVH f64 at 4 waves is
+//    now 5-7 % FASTER than at 3 (random_scene 800x450 @ 100 spp 2281 -> 2388, @ 1600 spp 2505 -> 2689) — with 428 instead of 288 B
+//    of spills per lane, 112 MB of scratch resident and 11.7 GB instead of 0.65 GB per 15 ms launch through the memory side
+//    (profile of that build: issue slots busy 87 %, L2 hit 78 %).  Kept at 3: eighteen times the traffic for 5 % is the wrong
+//    trade for a kernel that shares the memory system with whatever else a node runs; -DRT_WAVES_PER_SIMD=4 builds the other form.
+//    The generic f64 variant stays at 3 either way (4 waves with an 864-entry head: 672 B of spills, -3 %).
 //  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
 //    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
