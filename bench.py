@@ -77,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--no-f32", action="store_true", help="skip the extra f32 throughput measurement")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = sized to ~12 s)")
     ap.add_argument("--no-sort", action="store_true", help="run the wave-level kernel where the block-sorted one would be used")
+    ap.add_argument("--deterministic", action="store_true", help="RT_RENDER_DETERMINISTIC: the reproducible accumulation mode (one lane per pixel)")
     ap.add_argument("--exchange", default="rt", choices=("rt", "torch"),
                     help="all-reduce of the accumulation buffers: rt = rt_allreduce_accum (C-ABI, RCCL); torch = torch.distributed")
     ap.add_argument("--out-png", default="")
@@ -254,55 +255,14 @@ def main():
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     stats = torch.zeros(4, dtype=torch.int64, device=dev)
 
-    exchange = None
-    exchange_note = None
-    comm = None
-    if use_dist:
-        exchange = a.exchange
-        if exchange == "rt":
-            def bcast(b):
-                t = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if b is not None:
-                    t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
-                dist.broadcast(t, 0)
-                return bytes(t.cpu().numpy().tobytes())
-
-            def all_agree(ok):  # every rank takes the same route, or the collectives below would hang
-                f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(f, op=dist.ReduceOp.MIN)
-                return bool(f.item())
-
-            # 1. can every rank bind RCCL through the library (dlopen)?  (an id made here is simply dropped)
-            why = ""
-            try:
-                rt.comm_probe()
-                ok = True
-            except Exception as e:  # noqa: BLE001
-                ok, why = False, f"{type(e).__name__}: {e}"
-            if all_agree(ok):
-                # 2. the communicator (collective), then one known all-reduce through it
-                try:
-                    comm = rt.Comm(rank, world, bcast, local)
-                    probe = torch.ones(1024, dtype=torch.float32, device=dev)
-                    comm.all_reduce(probe)
-                    torch.cuda.synchronize(dev)
-                    ok = bool((probe == float(world)).all().item())
-                    why = "" if ok else "probe all-reduce gave a wrong sum"
-                except Exception as e:  # noqa: BLE001
-                    ok, why = False, f"{type(e).__name__}: {e}"
-                ok = all_agree(ok)
-            if not ok:
-                if comm is not None:
-                    comm.close()
-                    comm = None
-                exchange = "torch"
-                exchange_note = "rt exchange unavailable on some rank, torch.distributed used" + (f" (this rank: {why})" if why else "")
+    # the exchange step: rt_allreduce_accum through the C-ABI when every rank can take that route (renderer.Exchange checks it
+    # on all ranks and falls back to torch.distributed for ALL of them otherwise; the line then says so)
+    ex = rt.Exchange(rank, world, dist, dev, prefer=a.exchange) if use_dist else None
+    comm = ex.comm if ex else None
+    exchange_note = ex.note if ex else None
 
     def all_reduce(buf):
-        if comm is not None:
-            comm.all_reduce(buf)
-        else:
-            dist.all_reduce(buf)
+        ex.all_reduce(buf)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -323,7 +283,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if my_count:
-                ds.render_into(accum, i * step_spp_total + my_begin, my_count, seed=a.seed, precision=precision, stats=stats, no_sort=a.no_sort)
+                ds.render_into(accum, i * step_spp_total + my_begin, my_count, seed=a.seed, precision=precision, stats=stats, no_sort=a.no_sort, deterministic=a.deterministic)
             if events is not None:
                 e1.record()
                 events.append((e0, e1))
@@ -354,10 +314,8 @@ def main():
 
     K, Wm = a.steps, a.warmup
     dt, launch_ms, ar_ms = timed(a.precision, K, Wm, 0)
-    if comm is not None:
-        comm.all_reduce_stats(stats)
-    elif use_dist:
-        dist.all_reduce(stats)
+    if ex:
+        ex.all_reduce_stats(stats)
     st = stats.cpu().numpy().astype("float64")
     total_samples = float(W) * H * step_spp_total * K
     value = total_samples / dt / 1e6
@@ -375,7 +333,7 @@ def main():
                 accum.zero_()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ds.render_into(accum, (K + Wm + i) * a.spp, a.spp, seed=a.seed, precision=a.precision, no_sort=a.no_sort)
+                ds.render_into(accum, (K + Wm + i) * a.spp, a.spp, seed=a.seed, precision=a.precision, no_sort=a.no_sort, deterministic=a.deterministic)
                 e1.record()
                 ev.append((e0, e1))
             torch.cuda.synchronize(dev)
@@ -396,7 +354,9 @@ def main():
         has_bvh = d.bvh.n_nodes > 0
         has_medium = any(d.world[i].is_medium for i in range(d.n_world))
         real = "double" if a.precision == "f64" else "float"
-        if not a.no_sort and not has_bvh and (d.n_lights > 0 or has_medium):
+        if a.deterministic:
+            kernel_name = f"render_kernel<{real}, DET> (one lane per pixel, RT_RENDER_DETERMINISTIC)"
+        elif not a.no_sort and not has_bvh and (d.n_lights > 0 or has_medium):
             kernel_name = f"render_kernel_sorted<{real}> (block-sorted)"
         else:
             kernel_name = f"render_kernel<{real}> (persistent wave jobs)"
@@ -406,14 +366,19 @@ def main():
         if fps:
             achieved = fps * samples_per_launch / mean_launch_s / 1e12
             hbm_bytes = float(W) * H * 3 * 4 * 2  # accumulation buffer read + written once per launch
-            view = executed_view(a.scene, W, H, my_count, a.precision)
+            view = None if (a.deterministic or a.no_sort) else executed_view(a.scene, W, H, my_count, a.precision)
+            live_build = desc.split("build=")[1].split()[0] if "build=" in desc else None  # the library that just ran (rt_describe)
             roofline = {
                 "bound": "valu", "achieved": round(achieved, 4), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[a.precision], 5),
                 "traffic": view.get("hbm_bytes_per_launch") if view else None,
                 "kernel": kernel_name,
                 "flops_per_sample": fps, "samples_per_launch": samples_per_launch, "launch_ms": round(mean_launch_s * 1e3, 4),
-                "executed": ({k: view[k] for k in ("valu_lane_slot_frac", "valu_lanes_active_frac", "valu_issue_busy_frac", "from") if k in view}
+                # `traffic` and `executed` are LOOKED UP from the committed rocprofv3 PMC passes of this workload (profiles/), not
+                # measured by this run: `executed.build` / `.head` say which build those passes profiled, `build` which one ran now
+                "build": live_build,
+                "executed": (dict({k: view[k] for k in ("valu_lane_slot_frac", "valu_lanes_active_frac", "valu_issue_busy_frac", "from", "build", "head")
+                                   if k in view}, of_this_build=(view.get("build") == live_build and live_build is not None))
                              if view else None),
                 "hbm": {"bound": "hbm", "achieved": round(hbm_bytes / mean_launch_s / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(hbm_bytes / mean_launch_s / 1e9 / PEAK_HBM_GBS, 7), "algorithmic_bytes_per_launch": hbm_bytes},
@@ -454,8 +419,8 @@ def main():
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
-    if comm is not None:
-        comm.close()
+    if ex:
+        ex.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

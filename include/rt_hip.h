@@ -43,7 +43,10 @@ enum RtStatus {
 
 /* Arithmetic type the device path computes in. RT_F64 restates the reference's f64 arithmetic
  * operation-for-operation (primitive ids and t bit-exact against the oracle, frames equal to the oracle's
- * sample for sample: this is the mode every parity claim is made for).  RT_F32 is a throughput mode outside
+ * sample for sample: this is the mode every parity claim is made for; one stated exception: the vector divisions
+ * unit(v) and v / s go through a shared-reciprocal routine that is IEEE division for denominators |d| in
+ * [2^-400, 2^400) and numerators |n| in [2^-600, 2^600] or 0 — a scene with a radius or a direction length outside
+ * that range may differ from the reference in the last bit of a normal).  RT_F32 is a throughput mode outside
  * the parity bar: the tests hold it to >= 99.5 % identical ids and t within 5e-4 relative on the probe (f32
  * cancellation in the sphere quadratic at coordinates ~1000), and its images are an independent estimate at the
  * Monte-Carlo noise floor. */
@@ -191,8 +194,20 @@ typedef struct RtRenderParams {
     uint32_t flags;           /* RtRenderFlags, 0 = default */
 } RtRenderParams;
 /* RT_RENDER_NO_SORT: use the wave-level kernel even where the block-sorted one applies (same samples, same
- * sums up to the order of f64 additions; for A/B measurements and tests). */
-enum RtRenderFlags { RT_RENDER_NO_SORT = 1 };
+ * sums up to the order of the additions; for A/B measurements and tests).
+ *
+ * RT_RENDER_DETERMINISTIC: a reproducible accumulation mode.  The reference sums a pixel's samples into one f64 in
+ * sample order (src/ray_tracing.rs:98-112).  By DEFAULT this library does not: the block-sorted kernel adds a tile's
+ * samples to per-pixel f64 sums in LDS in the order its four waves finish them, and every launch with fewer than 64
+ * tiles per resident wave / block (every frame below ~12 Mpixel) is cut into sample chunks whose partial sums reach
+ * d_accum through f32 atomics in arrival order — two identical calls can differ in the last bit of a sum, and a grey
+ * level of the resolved image can flip.  With this flag ONE lane renders all of a pixel's samples of the launch, in
+ * index order, sums them in f64 in that order and adds the rounded sum to d_accum with one plain store: the same call
+ * gives the same bits on every run (and on every gfx950), and d_accum of a zeroed buffer is the reference's sum
+ * rounded to f32.  Cost: the wave-level kernel without sample chunks — no block regrouping, no streaming jobs;
+ * measured 0.70x (cornell_box 1024^2 @ 1024 spp per launch) to 0.95x (random_scene) of the default throughput, less
+ * on small frames with few samples.  Implies RT_RENDER_NO_SORT. */
+enum RtRenderFlags { RT_RENDER_NO_SORT = 1, RT_RENDER_DETERMINISTIC = 2 };
 
 /* d_stats: 4 x uint64 counters, ADDED to by rt_render:
  * [0] accepted samples, [1] ray casts (world.hit calls), [2] NaN retries, [3] samples dropped at the retry cap */
@@ -201,7 +216,8 @@ enum RtRenderFlags { RT_RENDER_NO_SORT = 1 };
 /* Select the device for the calling thread (hipSetDevice) and check that it is a gfx950. */
 int rt_init(int device);
 const char* rt_last_error(void);
-/* Human-readable build/device description, e.g. "rt_hip abi=1 gfx950 cu=256". */
+/* Human-readable build/device description, e.g. "rt_hip abi=1 gfx950 cu=256 clock_mhz=2400 build=3f9c0a1b2c4d"
+ * (build = hash of the device sources and flags the library was compiled from). */
 const char* rt_describe(void);
 
 /* Upload a flattened scene. Replaces: handing `&ObjectList`/`&Option<ObjectList>`/`Camera` to
@@ -240,7 +256,9 @@ int rt_render_rgb8(RtScene* scene, const RtRenderParams* params, uint8_t* d_rgb,
 /* No counterpart in the reference.  rt_render_rgb8 for callers that CANNOT ALLOCATE (HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): same kernels, same output, but the float sums and the job
  * counter live in a static device array of the library (RT_NOALLOC_MAX_PIXELS x 12 bytes + 256, held on every GPU
- * the library runs on until the process ends).  Calls no hipMalloc / hipFree / event creation.  Frames of more than
+ * the library runs on until the process ends).  ("Same output": the same as rt_render_rgb8 with the same flags — bit for bit
+ * with RT_RENDER_DETERMINISTIC, and up to the order of the additions without it, see RtRenderFlags.)
+ * Calls no hipMalloc / hipFree / event creation.  Frames of more than
  * RT_NOALLOC_MAX_PIXELS pixels are rejected with RT_ERR_INVALID.  rt_init(device) must have run on the device.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two scenes) race. */
 #define RT_NOALLOC_MAX_PIXELS (1024u * 1024u)

@@ -14,7 +14,7 @@ from ._build import build_all  # noqa: F401
 
 
 def __getattr__(name):  # renderer needs torch; keep `import` of the package itself light
-    if name in ("HostScene", "FlatHostScene", "DeviceScene", "render", "render_progressive", "save_checkpoint", "load_checkpoint", "resolve", "write_png", "init", "spp_shard", "Comm", "comm_probe", "SCENES", "DEFAULT_SEED", "EARTHMAP"):
+    if name in ("HostScene", "FlatHostScene", "DeviceScene", "render", "render_progressive", "save_checkpoint", "load_checkpoint", "resolve", "write_png", "init", "spp_shard", "Comm", "Exchange", "comm_probe", "SCENES", "DEFAULT_SEED", "EARTHMAP"):
         from . import renderer
         return getattr(renderer, name)
     raise AttributeError(name)

@@ -5,7 +5,7 @@ write the 8-bit image — with the hard-coded tuple / `CI` switch of ray_tracing
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ray_tracing_amd --scene cornell_box ...
 
 One process per GPU; under torchrun the spp range is sharded over the ranks and the float accumulation buffers are
-summed with one RCCL all-reduce.  Prints one JSON record (scene, seed, size, seconds, Msamples/s, casts/sample, NaN retries)."""
+summed with one RCCL all-reduce through the C-ABI (renderer.Exchange: rt_allreduce_accum; torch.distributed ships the id).  Prints one JSON record (scene, seed, size, seconds, Msamples/s, casts/sample, NaN retries)."""
 import argparse
 import json
 import os
@@ -28,6 +28,8 @@ def main(argv=None):
     ap.add_argument("--checkpoint", default="", help="progressive rendering: write the summed accumulation buffer here after every pass")
     ap.add_argument("--pass-spp", type=int, default=0, help="samples per pass (all GPUs together) between checkpoints; default: spp/8")
     ap.add_argument("--resume", action="store_true", help="continue the render recorded in --checkpoint (same scene, seed, size, depth)")
+    ap.add_argument("--exchange", default="rt", choices=("rt", "torch"),
+                    help="sum of the ranks' buffers: rt = rt_allreduce_accum (C-ABI, RCCL; falls back when a rank cannot), torch = torch.distributed")
     a = ap.parse_args(argv)
 
     import torch
@@ -44,6 +46,8 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     rt.init(local)
+    # the exchange step: the C-ABI's one RCCL all-reduce (rt_allreduce_accum) when every rank can take that route
+    ex = rt.Exchange(rank, world, dist, f"cuda:{local}", prefer=a.exchange) if world > 1 else None
     t0 = time.perf_counter()
     hs = rt.HostScene(a.scene, a.width / a.height, seed=a.seed)
     ds = rt.DeviceScene(hs, local)
@@ -55,16 +59,16 @@ def main(argv=None):
     if a.checkpoint:
         acc, spp_done = rt.render_progressive(ds, a.width, a.height, a.spp, a.pass_spp or max(1, a.spp // 8), seed=a.seed, max_depth=a.depth,
                                        precision=a.precision, spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
-                                       all_reduce=dist.all_reduce if world > 1 else None, stats=stats, checkpoint=a.checkpoint,
+                                       all_reduce=ex.all_reduce if ex else None, stats=stats, checkpoint=a.checkpoint,
                                        resume=a.resume, scene_name=a.scene)
     else:
         acc = rt.render(ds, a.width, a.height, a.spp, seed=a.seed, max_depth=a.depth, precision=a.precision,
                         spp_per_launch=a.spp_per_launch, rank=rank, world_size=world,
-                        all_reduce=dist.all_reduce if world > 1 else None, stats=stats)
+                        all_reduce=ex.all_reduce if ex else None, stats=stats)
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t0
-    if world > 1:
-        dist.all_reduce(stats)
+    if ex:
+        ex.all_reduce_stats(stats)
     if rank == 0:
         rgb = rt.resolve(acc, spp_done)  # the sums hold spp_done samples per pixel
         if a.out:
@@ -77,7 +81,10 @@ def main(argv=None):
         print(json.dumps({"scene": a.scene, "seed": a.seed, "width": a.width, "height": a.height, "spp": a.spp, "max_depth": a.depth,
                           "precision": a.precision, "n_gpus": world, "seconds_scene_build": round(t_build, 4),
                           "seconds_render": round(t_render, 4), "msamples_per_s": round(a.width * a.height * a.spp / t_render / 1e6, 3),
-                          "casts_per_sample": round(st[1] / max(st[0], 1), 4), "nan_retries": st[2], "dropped_samples": st[3], "out": a.out}))
+                          "casts_per_sample": round(st[1] / max(st[0], 1), 4), "nan_retries": st[2], "dropped_samples": st[3], "out": a.out,
+                          "exchange": (ex.route if ex else None), **({"exchange_note": ex.note} if ex and ex.note else {})}))
+    if ex:
+        ex.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,6 +42,21 @@ def _run(cmd):
         raise RuntimeError("build failed: " + " ".join(cmd))
 
 
+def source_id(defines=(), f64_flags=()):
+    """Identity of a build of librt_hip.so: a hash of every source the device code is made of (csrc/, include/rt_hip.h) and of the
+    flags.  The library reports it (rt_describe: "build=<id>"), bench.py prints it, and tools/pmc_summary.py stores it with every
+    profile summary, so a number looked up from profiles/ can be told from one measured on the build that ran."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".hip")))
+    for f in files:
+        h.update(f.encode() + b"\0" + open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rt_hip.h"), "rb").read())
+    h.update(repr((UNITS, COMMON[1:], sorted(defines), list(f64_flags))).encode())
+    return h.hexdigest()[:12]
+
+
 def build_hip(force=False, defines=(), out=None, tag="", f64_flags=()):
     """defines/out/tag/f64_flags: build an A/B variant library (tools/build_ab.py) beside the product one."""
     global LIB_HIP
@@ -49,12 +64,18 @@ def build_hip(force=False, defines=(), out=None, tag="", f64_flags=()):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "rt_hip.h"))
+    all_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")]
+    build_id = source_id(defines, f64_flags)
     objs = []
     for src, flags in UNITS:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", tag + ".o"))
-        if force or _newer(o, [s] + headers):
+        # rt_hip.hip carries the build id of ALL the sources: rebuilt when any of them changes
+        deps = [s] + headers + (all_src if src == "rt_hip.hip" else [])
+        if force or _newer(o, deps):
             extra = list(f64_flags) if src == "rt_kernels_f64.hip" else []
+            if src == "rt_hip.hip":
+                extra.append('-DRT_BUILD_ID="%s"' % build_id)
             _run([HIPCC] + COMMON + flags + extra + ["-D" + d for d in defines] + ["-c", s, "-o", o])
         objs.append(o)
     if force or _newer(lib_out, objs):

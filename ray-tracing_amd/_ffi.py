@@ -9,6 +9,7 @@ LIB_HOST = os.path.join(PKG, "librt_host.so")
 
 RT_F32, RT_F64 = 0, 1
 RT_STATS_WORDS = 4
+RT_RENDER_NO_SORT, RT_RENDER_DETERMINISTIC = 1, 2  # RtRenderFlags
 RT_COMM_ID_BYTES = 128
 RT_NOALLOC_MAX_PIXELS = 1024 * 1024
 

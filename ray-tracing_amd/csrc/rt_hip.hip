@@ -12,6 +12,10 @@
 #include "rt_launch.hpp"
 #include "rt_pack.hpp"
 
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"  // _build.py: hash of the device sources and flags this library was built from
+#endif
+
 namespace {
 
 thread_local std::string g_desc;
@@ -122,7 +126,7 @@ int rt_init(int device) {
         g_scratch_ptr[device] = (unsigned char*)p;
     }
     g_desc = "rt_hip abi=" + std::to_string(RT_ABI_VERSION) + " " + prop.gcnArchName + " cu=" + std::to_string(prop.multiProcessorCount) +
-             " clock_mhz=" + std::to_string(prop.clockRate / 1000);
+             " clock_mhz=" + std::to_string(prop.clockRate / 1000) + " build=" RT_BUILD_ID;
     return RT_OK;
 }
 
@@ -218,7 +222,8 @@ static int make_args(const RtRenderParams* p, rt::RenderArgs& a) {
 // One render launch with the job-counter word the caller chose (ring slot of the scene, or static scratch).
 static int render_launch(RtScene* scene, const RtRenderParams* params, const rt::RenderArgs& a, uint32_t* d_counter, float* d_accum,
                          uint64_t* d_stats, hipStream_t stream) {
-    const rt::LaunchCtx ctx{d_counter, scene->cu_count};
+    if (params->flags & ~(uint32_t)(RT_RENDER_NO_SORT | RT_RENDER_DETERMINISTIC)) return fail(RT_ERR_INVALID, "unknown bits in RtRenderParams.flags");
+    const rt::LaunchCtx ctx{d_counter, scene->cu_count, (params->flags & RT_RENDER_DETERMINISTIC) != 0};
     const bool no_sort = (params->flags & RT_RENDER_NO_SORT) != 0;
     if (params->precision == RT_F64) HIP_TRY(rt::launch_render<double>(scene->s64, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, stream));
     else if (params->precision == RT_F32) HIP_TRY(rt::launch_render<float>(scene->s32, scene->features, a, no_sort, ctx, d_accum, (unsigned long long*)d_stats, stream));
@@ -230,8 +235,10 @@ static int render_launch(RtScene* scene, const RtRenderParams* params, const rt:
 static int ring_acquire(RtScene* scene, hipStream_t stream, uint32_t& slot, bool& capturing) {
     slot = scene->next_counter++ % RtScene::kCounters;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    if (hipGetLastError() != hipSuccess) {}  // (a legacy-stream query during another stream's capture only sets the sticky error)
+    const hipError_t qe = hipStreamIsCapturing(stream, &cs);
+    capturing = qe == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (qe != hipSuccess) (void)hipGetLastError();  // (a legacy-stream query during another stream's capture fails and leaves its code
+                                                    // behind: that one is dropped; an error pending from before stays for its owner)
     if (scene->slot_recorded[slot] && scene->slot_stream[slot] != stream && !capturing)
         HIP_TRY(hipStreamWaitEvent(stream, scene->slot_event[slot], 0));
     return RT_OK;

@@ -9,7 +9,8 @@ namespace rt {
 
 // What a render launch needs from the scene handle besides the scene: a zeroable device word for the persistent
 // kernel's job counter (one per launch in flight) and the device's CU count.
-struct LaunchCtx { uint32_t* job_counter; uint32_t cu_count; };
+// deterministic: RT_RENDER_DETERMINISTIC (rt_hip.h) — the wave kernel's one-lane-per-pixel form, one chunk per tile.
+struct LaunchCtx { uint32_t* job_counter; uint32_t cu_count; bool deterministic; };
 template <class T> hipError_t launch_render(const DScene<T>& sc, uint32_t features, const RenderArgs& a, bool no_sort, const LaunchCtx& ctx,
                                            float* d_accum, unsigned long long* d_stats, hipStream_t stream);
 template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t features, uint32_t width, uint32_t height, double time,

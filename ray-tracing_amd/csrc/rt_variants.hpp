@@ -9,6 +9,7 @@ constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                              
 constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, checker spheres
 constexpr uint32_t V_SPHERES_FLAT = V_SPHERES & ~F_BVH;                                                      // earth, two_checker_spheres (no LDS node table)
 constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                                               // two_perlin_spheres
+constexpr uint32_t V_FINAL = 0x3fffu & ~F_FROSTED;  // final_scene: every feature but FrostedDielectric (only random_scene_light has one)
 
 // Register budget of the persistent render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
 // SIMD: 2 -> 256, 3 -> 168, 4 -> 128), and the LDS budget of the staged BVH head (32-byte entries), sized so that
@@ -97,5 +98,6 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
         else if (((features) & ~rt::V_SPHERES_FLAT) == 0) { CALL(rt::V_SPHERES_FLAT); } \
         else if (((features) & ~rt::V_SPHERES) == 0) { CALL(rt::V_SPHERES); }\
         else if (((features) & ~rt::V_NOISE) == 0) { CALL(rt::V_NOISE); }    \
+        else if (((features) & ~rt::V_FINAL) == 0) { CALL(rt::V_FINAL); }    \
         else { CALL(rt::F_ALL); }                                            \
     } while (0)

@@ -29,6 +29,7 @@ struct Options {
     int depth = 50, gpus = 1;                                                   // ray_tracing.rs:105
     uint64_t seed = 0x5EED0001ull;
     uint32_t precision = RT_F64;
+    bool deterministic = false;  // RT_RENDER_DETERMINISTIC: reproducible bits (one lane per pixel, samples summed in order)
 };
 
 [[noreturn]] void die(const std::string& msg) {
@@ -59,9 +60,10 @@ Options parse(int argc, char** argv) {
             if (p == "f64") o.precision = RT_F64;
             else if (p == "f32") o.precision = RT_F32;
             else die("--precision must be f64 or f32");
-        } else if (k == "--help" || k == "-h") {
+        } else if (k == "--deterministic") o.deterministic = true;
+        else if (k == "--help" || k == "-h") {
             std::printf("usage: rt_render [--scene NAME] [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--precision f64|f32]\n"
-                        "                 [--spp-per-launch K] [--gpus N] [--image earthmap.(jpg|ppm)] [--out file.png]\nscenes:");
+                        "                 [--spp-per-launch K] [--gpus N] [--deterministic] [--image earthmap.(jpg|ppm)] [--out file.png]\nscenes:");
             for (const char* const* n = rth_scene_names(); *n; n++) std::printf(" %s", *n);
             std::printf("\n");
             std::exit(0);
@@ -139,33 +141,63 @@ struct Shared {
     const Options* opt;
     const RtSceneDesc* desc;
     uint8_t comm_id[RT_COMM_ID_BYTES];
-    std::atomic<int> failed{0};
+    std::atomic<int> failed{0}, arrived{0};
     std::string error[64];
     std::vector<uint8_t> rgb;      // GPU 0: the resolved image
     uint64_t stats[RT_STATS_WORDS] = {0, 0, 0, 0};
     double seconds_render = 0.0;
 };
 
+// Failures BEFORE the communicator exists are recorded and agreed on by all GPU threads (nobody enters a collective unless every
+// thread's set-up succeeded).  Once a collective may be pending, one thread that simply returned would leave the others blocked in
+// rt_comm_create / rt_allreduce_accum / rt_stream_synchronize for ever: from there on a failure prints its message and ends the
+// whole process.
 #define CHECK(expr)                                                                                      \
     do {                                                                                                 \
-        if ((expr) != RT_OK) { sh->error[g] = std::string(#expr) + ": " + rt_last_error(); sh->failed++; return; } \
+        if ((expr) != RT_OK) { sh->error[g] = std::string(#expr) + ": " + rt_last_error(); return false; } \
     } while (0)
+#define FATAL(expr)                                                                                      \
+    do {                                                                                                 \
+        if ((expr) != RT_OK) {                                                                           \
+            std::fprintf(stderr, "rt_render: GPU %d: %s: %s\n", g, #expr, rt_last_error());             \
+            std::fflush(stderr);                                                                         \
+            std::_Exit(1);                                                                               \
+        }                                                                                                \
+    } while (0)
+
+struct Gpu {
+    RtScene* scene = nullptr;
+    void *d_accum = nullptr, *d_stats = nullptr;
+    uint64_t floats = 0;
+};
+
+// everything that can fail for reasons of this GPU alone (out of memory, a scene the device rejects): before any collective
+bool gpu_setup(Shared* sh, int g, Gpu& r) {
+    const Options& o = *sh->opt;
+    CHECK(rt_init(g));  // (selects the device for this thread)
+    CHECK(rt_scene_create(sh->desc, &r.scene));
+    r.floats = (uint64_t)o.width * o.height * 3u;
+    CHECK(rt_device_alloc(&r.d_accum, r.floats * sizeof(float)));
+    CHECK(rt_device_alloc(&r.d_stats, RT_STATS_WORDS * sizeof(uint64_t)));
+    CHECK(rt_device_zero(r.d_accum, r.floats * sizeof(float), nullptr));
+    CHECK(rt_device_zero(r.d_stats, RT_STATS_WORDS * sizeof(uint64_t), nullptr));
+    CHECK(rt_stream_synchronize(nullptr));
+    return true;
+}
 
 void gpu_thread(Shared* sh, int g) {
     const Options& o = *sh->opt;
     const int n = o.gpus;
-    CHECK(rt_init(g));  // (selects the device for this thread)
+    Gpu r;
+    if (!gpu_setup(sh, g, r)) sh->failed++;
+    sh->arrived++;
+    while (sh->arrived.load() < n) std::this_thread::yield();  // every thread has counted itself in, failed or not
+    if (sh->failed.load() != 0) return;                        // (main prints the messages; the process ends, device memory with it)
     RtComm* comm = nullptr;
-    if (n > 1) CHECK(rt_comm_create(sh->comm_id, n, g, &comm));  // collective: every GPU's thread is here
-    RtScene* scene = nullptr;
-    CHECK(rt_scene_create(sh->desc, &scene));
-    const uint64_t floats = (uint64_t)o.width * o.height * 3u;
-    void *d_accum = nullptr, *d_stats = nullptr, *d_rgb = nullptr;
-    CHECK(rt_device_alloc(&d_accum, floats * sizeof(float)));
-    CHECK(rt_device_alloc(&d_stats, RT_STATS_WORDS * sizeof(uint64_t)));
-    CHECK(rt_device_zero(d_accum, floats * sizeof(float), nullptr));
-    CHECK(rt_device_zero(d_stats, RT_STATS_WORDS * sizeof(uint64_t), nullptr));
-    CHECK(rt_stream_synchronize(nullptr));
+    if (n > 1) FATAL(rt_comm_create(sh->comm_id, n, g, &comm));  // collective: every GPU's thread is here
+    const uint64_t floats = r.floats;
+    void *d_accum = r.d_accum, *d_stats = r.d_stats, *d_rgb = nullptr;
+    RtScene* scene = r.scene;
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t begin, count;
     spp_shard(o.spp, g, n, begin, count);
@@ -174,28 +206,28 @@ void gpu_thread(Shared* sh, int g) {
         RtRenderParams p;
         std::memset(&p, 0, sizeof p);
         p.width = o.width; p.height = o.height; p.spp_begin = s; p.spp_count = k; p.max_depth = o.depth;
-        p.max_nan_retries = 64; p.seed = o.seed; p.precision = o.precision; p.flags = 0;
-        CHECK(rt_render(scene, &p, (float*)d_accum, (uint64_t*)d_stats, nullptr));
+        p.max_nan_retries = 64; p.seed = o.seed; p.precision = o.precision; p.flags = o.deterministic ? RT_RENDER_DETERMINISTIC : 0u;
+        FATAL(rt_render(scene, &p, (float*)d_accum, (uint64_t*)d_stats, nullptr));
         s += k;
     }
     if (comm) {  // the path's one exchange step (ray_tracing.rs:119-131: the gather into the single image)
-        CHECK(rt_allreduce_accum(comm, (float*)d_accum, floats, nullptr));
-        CHECK(rt_allreduce_stats(comm, (uint64_t*)d_stats, nullptr));
+        FATAL(rt_allreduce_accum(comm, (float*)d_accum, floats, nullptr));
+        FATAL(rt_allreduce_stats(comm, (uint64_t*)d_stats, nullptr));
     }
-    CHECK(rt_stream_synchronize(nullptr));
+    FATAL(rt_stream_synchronize(nullptr));
     if (g == 0) {
         sh->seconds_render = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        CHECK(rt_device_alloc(&d_rgb, floats));
-        CHECK(rt_resolve((const float*)d_accum, o.width, o.height, o.spp, (uint8_t*)d_rgb, nullptr));  // ray_tracing.rs:112-117,126-128
+        FATAL(rt_device_alloc(&d_rgb, floats));
+        FATAL(rt_resolve((const float*)d_accum, o.width, o.height, o.spp, (uint8_t*)d_rgb, nullptr));  // ray_tracing.rs:112-117,126-128
         sh->rgb.resize(floats);
-        CHECK(rt_copy_to_host(sh->rgb.data(), d_rgb, floats, nullptr));
-        CHECK(rt_copy_to_host(sh->stats, d_stats, sizeof sh->stats, nullptr));
-        CHECK(rt_device_free(d_rgb));
+        FATAL(rt_copy_to_host(sh->rgb.data(), d_rgb, floats, nullptr));
+        FATAL(rt_copy_to_host(sh->stats, d_stats, sizeof sh->stats, nullptr));
+        FATAL(rt_device_free(d_rgb));
     }
-    CHECK(rt_device_free(d_accum));
-    CHECK(rt_device_free(d_stats));
-    if (comm) CHECK(rt_comm_destroy(comm));
-    CHECK(rt_scene_destroy(scene));
+    FATAL(rt_device_free(d_accum));
+    FATAL(rt_device_free(d_stats));
+    if (comm) FATAL(rt_comm_destroy(comm));
+    FATAL(rt_scene_destroy(scene));
 }
 
 }  // namespace

@@ -25,6 +25,10 @@ _PRECISION = {"f32": RT_F32, "f64": RT_F64, RT_F32: RT_F32, RT_F64: RT_F64}
 _inited = set()
 
 
+def _flags(no_sort=False, deterministic=False):
+    return (_ffi.RT_RENDER_NO_SORT if no_sort else 0) | (_ffi.RT_RENDER_DETERMINISTIC if deterministic else 0)
+
+
 def init(device=0):
     """rt_init: select the GPU for this process (one process per GPU)."""
     check(_ffi.hip().rt_init(int(device)))
@@ -121,22 +125,23 @@ class DeviceScene:
         return ids, ts
 
     def render_into(self, accum, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
-                    max_nan_retries=64, no_sort=False):
-        """accum: float32 CUDA tensor [H, W, 3] (row = y upward), ADDED to. stats: uint64-as-int64 tensor [4] or None."""
+                    max_nan_retries=64, no_sort=False, deterministic=False):
+        """accum: float32 CUDA tensor [H, W, 3] (row = y upward), ADDED to. stats: uint64-as-int64 tensor [4] or None.
+        deterministic: RT_RENDER_DETERMINISTIC (one lane per pixel, samples summed in index order: reproducible bits)."""
         assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous() and accum.dim() == 3 and accum.shape[2] == 3
         h, w = accum.shape[0], accum.shape[1]
         p = RtRenderParams(w, h, int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
-                           _PRECISION[precision], 1 if no_sort else 0)
+                           _PRECISION[precision], _flags(no_sort, deterministic))
         sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
         with torch.cuda.device(self.device):
             check(_ffi.hip().rt_render(self._h, C.byref(p), C.c_void_p(accum.data_ptr()), sp, self._stream()))
 
     def render_rgb8(self, width, height, spp_begin, spp_count, seed=DEFAULT_SEED, max_depth=50, precision="f32", stats=None,
-                    max_nan_retries=64, no_sort=False, noalloc=False, out=None):
+                    max_nan_retries=64, no_sort=False, noalloc=False, out=None, deterministic=False):
         """ray_tracing.rs:95-118 in one call -> uint8 CUDA tensor [H, W, 3], top row first (rt_render_rgb8, or the
         allocation-free rt_render_rgb8_noalloc with noalloc=True; `out` = a preallocated result tensor)."""
         p = RtRenderParams(int(width), int(height), int(spp_begin), int(spp_count), int(max_depth), int(max_nan_retries), int(seed),
-                           _PRECISION[precision], 1 if no_sort else 0)
+                           _PRECISION[precision], _flags(no_sort, deterministic))
         sp = C.c_void_p(stats.data_ptr()) if stats is not None else C.c_void_p()
         with torch.cuda.device(self.device):
             rgb = out if out is not None else torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
@@ -233,6 +238,81 @@ class Comm:
             pass
 
 
+class Exchange:
+    """The exchange step of a multi-process render, as every launcher of this package uses it (`python -m ray_tracing_amd`,
+    bench.py): the C-ABI route — rt_comm_* + rt_allreduce_accum, ONE RCCL all-reduce of the float sums — when EVERY rank can
+    take it, else torch.distributed for all of them.  Ranks must agree on the route or the collectives would hang, so the
+    choice itself is two small torch.distributed reductions: (1) can this rank bind RCCL through the library, (2) did the
+    communicator come up and does a known all-reduce through it sum right.  torch.distributed otherwise only ships the
+    128-byte communicator id.  `dist`: the initialised torch.distributed module; `device`: where the control tensors live
+    (the rank's GPU; "cpu" under gloo, where step 1 or 2 fails and the fallback is what runs)."""
+
+    def __init__(self, rank, world_size, dist, device, prefer="rt"):
+        self.rank, self.world_size, self.dist = int(rank), int(world_size), dist
+        self.device = torch.device(device)
+        self.comm, self.route, self.note = None, "torch", None
+        if prefer != "rt":
+            return
+        why = ""
+        try:
+            if self.device.type != "cuda":
+                raise _ffi.RtError("no GPU on this rank")
+            comm_probe()
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if self._all_agree(ok):
+            try:
+                self.comm = Comm(self.rank, self.world_size, self._bcast, self.device.index)
+                probe = torch.ones(1024, dtype=torch.float32, device=self.device)
+                self.comm.all_reduce(probe)
+                torch.cuda.synchronize(self.device)
+                ok = bool((probe == float(self.world_size)).all().item())
+                why = "" if ok else "probe all-reduce gave a wrong sum"
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"{type(e).__name__}: {e}"
+            ok = self._all_agree(ok)
+        if ok:
+            self.route = "rt"
+        else:
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            self.note = "rt exchange unavailable on some rank, torch.distributed used" + (f" (this rank: {why})" if why else "")
+
+    def _bcast(self, b):
+        t = torch.zeros(_ffi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+        if b is not None:
+            t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+        self.dist.broadcast(t, 0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def _all_agree(self, ok):
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(f, op=self.dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    def all_reduce(self, buf):
+        """In-place sum over the ranks of a float32 buffer (the accumulation buffer)."""
+        if self.comm is not None:
+            self.comm.all_reduce(buf)
+        else:
+            self.dist.all_reduce(buf)
+        return buf
+
+    def all_reduce_stats(self, stats):
+        if self.comm is not None:
+            self.comm.all_reduce_stats(stats)
+        else:
+            self.dist.all_reduce(stats)
+        return stats
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
 def spp_shard(spp, rank, world_size):
     """GPU g of N renders samples [g*spp/N, (g+1)*spp/N) of every pixel (disjoint RNG keys)."""
     return spp * rank // world_size, spp * (rank + 1) // world_size - spp * rank // world_size
@@ -240,8 +320,9 @@ def spp_shard(spp, rank, world_size):
 
 def render(scene, width, height, spp, seed=DEFAULT_SEED, max_depth=50, precision="f32", spp_per_launch=None,
            rank=0, world_size=1, all_reduce=None, stats=None):
-    """Render this rank's spp shard into a fresh accumulation buffer; if all_reduce is given
-    (e.g. torch.distributed.all_reduce) sum the buffers over ranks.  Returns accum [H,W,3] f32."""
+    """Render this rank's spp shard into a fresh accumulation buffer; if all_reduce is given (Exchange.all_reduce: the
+    C-ABI's rt_allreduce_accum; any callable that sums a float32 tensor in place over the ranks) sum the buffers over
+    ranks.  Returns accum [H,W,3] f32."""
     accum = torch.zeros((height, width, 3), dtype=torch.float32, device=scene.torch_device)
     begin, count = spp_shard(spp, rank, world_size)
     step = spp_per_launch or count or 1
@@ -316,10 +397,14 @@ def render_progressive(scene, width, height, spp, pass_spp, seed=DEFAULT_SEED, m
             accum += torch.from_numpy(arr).to(accum.device)
     if all_reduce is not None and world_size > 1:
         # every rank must start from the same sample count (a checkpoint file that only some ranks can see would make
-        # the passes, and with them the all-reduce calls, differ): sum d and d^2 over the ranks; all equal <=> N*sum(d^2) == sum(d)^2
-        chk = torch.tensor([float(done), float(done) * float(done)], dtype=torch.float64, device=accum.device)
+        # the passes, and with them the all-reduce calls, differ).  The callback sums FLOAT32 buffers (rt_allreduce_accum has no
+        # other type), so the count travels as its four bytes b and their squares, all exact in f32 up to 64 ranks:
+        # the ranks agree on a byte <=> N * sum(b^2) == sum(b)^2
+        by = [float((done >> (8 * k)) & 0xFF) for k in range(4)]
+        chk = torch.tensor(by + [b * b for b in by], dtype=torch.float32, device=accum.device)
         all_reduce(chk)
-        if abs(world_size * chk[1].item() - chk[0].item() ** 2) > 0.5:
+        c = chk.tolist()
+        if any(abs(world_size * c[4 + k] - c[k] ** 2) > 0.5 for k in range(4)):
             raise ValueError(f"ranks disagree on the checkpoint's spp_done (this rank: {done}): put {checkpoint} where every rank reads the same file")
     while done < spp:
         n = min(int(pass_spp), spp - done)

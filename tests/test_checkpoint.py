@@ -56,13 +56,30 @@ def _worker(rank, world, port, out_dir):
     try:
         sc = OracleBackedScene("cornell_box")
         path = os.path.join(out_dir, "two.rtck")
+        ex = rt.Exchange(rank, world, dist, "cpu")  # (falls back to torch.distributed on CPU: tests/test_distributed_cpu.py)
+
+        def f32_sum(buf):  # the exchange of the C-ABI sums float32 buffers and nothing else: so must every caller
+            assert buf.dtype == torch.float32 and buf.is_contiguous()
+            return ex.all_reduce(buf)
+
         # first 5 samples here ...
-        rt.render_progressive(sc, W, H, 5, 5, rank=rank, world_size=world, all_reduce=dist.all_reduce, checkpoint=path, scene_name="cornell_box")
+        rt.render_progressive(sc, W, H, 5, 5, rank=rank, world_size=world, all_reduce=f32_sum, checkpoint=path, scene_name="cornell_box")
         dist.barrier()
         # ... the rest continued from the file, in passes of 3 split over the two ranks
-        acc, done = rt.render_progressive(sc, W, H, SPP, 3, rank=rank, world_size=world, all_reduce=dist.all_reduce, checkpoint=path,
+        acc, done = rt.render_progressive(sc, W, H, SPP, 3, rank=rank, world_size=world, all_reduce=f32_sum, checkpoint=path,
                                           resume=True, scene_name="cornell_box")
         assert done == SPP
+        # ranks that disagree on where to resume (a checkpoint only rank 0 can see) are told so instead of hanging in unequal passes
+        lonely = os.path.join(out_dir, "only_rank0.rtck")
+        if rank == 0:
+            rt.save_checkpoint(lonely, acc, dict(scene="cornell_box", seed=rt.DEFAULT_SEED, max_depth=50, spp_done=4, precision="f32"))
+        dist.barrier()
+        try:
+            rt.render_progressive(sc, W, H, SPP, 3, rank=rank, world_size=world, all_reduce=f32_sum,
+                                  checkpoint=lonely if rank == 0 else lonely + ".absent", resume=True, scene_name="cornell_box")
+            raise AssertionError("ranks with different resume points must be refused")
+        except ValueError as e:
+            assert "disagree" in str(e)
         np.save(os.path.join(out_dir, f"acc_{rank}.npy"), acc.numpy())
     finally:
         dist.destroy_process_group()

@@ -40,7 +40,21 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sc = OracleBackedScene("cornell_box")
-        acc = rt.render(sc, W, H, SPP, rank=rank, world_size=world, all_reduce=dist.all_reduce, spp_per_launch=3)
+        # the launchers' exchange object (renderer.Exchange): without a GPU the C-ABI route cannot come up on any rank, ALL ranks
+        # must agree on the torch.distributed route (the selection logic is what runs here), and say why
+        ex = rt.Exchange(rank, world, dist, "cpu")
+        assert ex.route == "torch" and ex.comm is None and "torch.distributed used" in ex.note and "no GPU" in ex.note
+        assert rt.Exchange(rank, world, dist, "cpu", prefer="torch").note is None  # asked for: nothing to explain
+
+        def f32_sum(buf):  # what rt_allreduce_accum can do: float32, in place
+            assert buf.dtype == torch.float32 and buf.is_contiguous()
+            return ex.all_reduce(buf)
+
+        acc = rt.render(sc, W, H, SPP, rank=rank, world_size=world, all_reduce=f32_sum, spp_per_launch=3)
+        st = torch.tensor([rank + 1, 10, 0, 0], dtype=torch.int64)
+        ex.all_reduce_stats(st)
+        assert st.tolist() == [sum(range(1, world + 1)), 10 * world, 0, 0]
+        ex.close()
         np.save(os.path.join(out_dir, f"acc_{rank}.npy"), acc.numpy())
     finally:
         dist.destroy_process_group()

@@ -116,10 +116,9 @@ def test_render_f64_equals_oracle_frame(name, scenes):
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
     stats = torch.zeros(4, dtype=torch.int64, device="cuda:0")
     ds.render_into(acc, 3, spp, precision="f64", stats=stats)  # samples 3..8: a shard that does not start at 0
-    ref, cnt = OracleScene(name, 1.0).render(W, H, 3, spp, threads=8)
-    got = acc.cpu().numpy().astype(np.float64)
-    close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)  # f32 accumulation buffer
-    assert close.mean() >= 0.998, f"{name}: {close.mean():.4f} of pixels equal the oracle"
+    oc = OracleScene(name, 1.0)
+    ref, cnt = oc.render(W, H, 3, spp, threads=8)
+    frame_close(f"render_f64_equals_oracle_frame[{name}]", acc.cpu().numpy(), ref, ds, oc, 3, spp)  # (2e-6: the f32 accumulation buffer)
     st = stats.cpu().numpy()
     assert st[0] == W * H * spp and st[3] == 0
     assert abs(int(st[1]) - cnt["casts"]) <= 0.002 * cnt["casts"]  # same paths -> same number of ray casts
@@ -235,9 +234,9 @@ def test_wave_kernel_and_sorted_kernel_agree(name, scenes):
     ds.render_into(b, 2, spp, precision="f64", stats=sb, no_sort=True)
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     assert sa.tolist() == sb.tolist() and sa[0].item() == W * H * spp
-    ref, cnt = OracleScene(name, 1.0).render(W, H, 2, spp, threads=8)
-    close = (np.abs(a.cpu().numpy() - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
-    assert close.mean() >= 0.998
+    oc = OracleScene(name, 1.0)
+    ref, cnt = oc.render(W, H, 2, spp, threads=8)
+    frame_close(f"sorted_and_wave_kernels[{name}]", a.cpu().numpy(), ref, ds, oc, 2, spp)
     assert abs(int(sa[1]) - cnt["casts"]) <= 0.002 * cnt["casts"]
 
 
@@ -247,14 +246,13 @@ def test_persistent_kernel_sample_chunks(name, W, H, spp, scenes):
     # waves / blocks render concurrently and add with float atomics.  The frame must still be the oracle's, every
     # sample counted once.
     ds = scenes(name, W / H)
-    ref, cnt = OracleScene(name, W / H).render(W, H, 3, spp, threads=8)
+    oc = OracleScene(name, W / H)
+    ref, cnt = oc.render(W, H, 3, spp, threads=8)
     for no_sort in (True, False):  # (False selects the block-sorted kernel for cornell_box only)
         a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
         st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
         ds.render_into(a, 3, spp, precision="f64", stats=st, no_sort=no_sort)
-        got = a.cpu().numpy().astype(np.float64)
-        close = (np.abs(got - ref) <= 4e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
-        assert close.mean() >= 0.995, (name, no_sort, close.mean())
+        frame_close(f"sample_chunks[{name},no_sort={no_sort}]", a.cpu().numpy(), ref, ds, oc, 3, spp, rtol=4e-6, floor=0.995)
         assert st[0].item() + st[3].item() == W * H * spp
         assert abs(int(st[1]) - cnt["casts"]) <= 0.003 * cnt["casts"] + 2
         # two launches of half the samples add up to the same frame
@@ -366,9 +364,7 @@ def test_random_flat_scene_gpu_equals_oracle(seed, gpu):
             acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
             st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
             ds.render_into(acc, 0, spp, precision="f64", stats=st, no_sort=no_sort)
-            got = acc.cpu().numpy().astype(np.float64)
-            close = (np.abs(got - ref) <= 2e-6 * np.maximum(np.abs(ref), 1.0)).all(axis=2)
-            assert close.mean() >= 0.995, (seed, no_sort, close.mean())
+            frame_close(f"flat_fuzz[{seed},no_sort={no_sort}]", acc.cpu().numpy(), ref, ds, oc, 0, spp, floor=0.995)
             assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
@@ -397,7 +393,7 @@ def test_json_scene_fixture_gpu(fixture, gpu, golden_dir):
         acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
         st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
         ds.render_into(acc, 0, spp, precision="f64", stats=st)
-        close = (np.abs(acc.cpu().numpy() - ref_f) <= 2e-6 * np.maximum(np.abs(ref_f), 1.0)).all(axis=2)
-        assert close.mean() >= 0.995 and abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+        frame_close(f"json_fixture[{fixture}]", acc.cpu().numpy(), ref_f, ds, oc, 0, spp, floor=0.995)
+        assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()

@@ -1,6 +1,15 @@
 """rt_render_rgb8_noalloc (include/rt_hip.h): the allocation-free variant of rt_render_rgb8 — float sums and job counter
 in the library's static device array — against rt_render_rgb8, through the C-ABI, two calls in a row, the second with
-a smaller frame (the array keeps the first call's contents)."""
+a smaller frame (the array keeps the first call's contents).
+
+What "equal" can mean here (VERDICT r2 / ADVICE r2): both entry points run the SAME kernels, and by default those kernels
+are not reproducible to the bit — random_scene's persistent wave kernel cuts a 384x256 frame into sample chunks whose
+partial sums reach the frame through f32 atomics in arrival order, and cornell_box's block-sorted kernel adds a tile's
+samples to f64 sums in LDS in the order its waves finish them.  So:
+  * with RT_RENDER_DETERMINISTIC (one lane per pixel, samples summed in index order) the two entry points must agree
+    BIT FOR BIT, on both scenes;
+  * without it they agree up to one grey level on at most 1e-3 of the values (as test_render_rgb8_equals_render_then_resolve
+    allows between two default launches), and exactly in the sample / cast / retry counters."""
 import ctypes as C
 
 import pytest
@@ -11,24 +20,46 @@ from ray_tracing_amd import _ffi
 
 pytestmark = pytest.mark.gpu
 
+FRAMES = ((384, 256, 33, 0), (120, 80, 40, 7))  # (W, H, spp, first sample): the second call is smaller
+
 
 @pytest.mark.parametrize("name", ("cornell_box", "random_scene"))
 def test_noalloc_equals_rgb8_two_calls_second_smaller(name, gpu):
     hs = rt.HostScene(name, 1.5)
     ds = rt.DeviceScene(hs, 0)
     try:
-        # spp in [32, 64): both render kernels run one sample chunk per tile, so the sums are order-independent and
-        # the two entry points must agree BIT FOR BIT
-        for (W, H, spp, s0) in ((384, 256, 33, 0), (120, 80, 40, 7)):
+        for (W, H, spp, s0) in FRAMES:
+            st_a = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+            st_b = torch.zeros_like(st_a)
+            want = ds.render_rgb8(W, H, s0, spp, precision="f64", stats=st_a, deterministic=True)
+            out = torch.full((H, W, 3), 77, dtype=torch.uint8, device="cuda:0")
+            got = ds.render_rgb8(W, H, s0, spp, precision="f64", stats=st_b, noalloc=True, out=out, deterministic=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (name, W, H)
+            assert st_a.tolist() == st_b.tolist() and st_a[0].item() == W * H * spp
+            assert got.float().std().item() > 1.0  # an image, not a constant
+    finally:
+        ds.close()
+        hs.close()
+
+
+@pytest.mark.parametrize("name", ("cornell_box", "random_scene"))
+def test_noalloc_default_kernels_within_one_grey_level(name, gpu):
+    hs = rt.HostScene(name, 1.5)
+    ds = rt.DeviceScene(hs, 0)
+    try:
+        for (W, H, spp, s0) in FRAMES:
             st_a = torch.zeros(4, dtype=torch.int64, device="cuda:0")
             st_b = torch.zeros_like(st_a)
             want = ds.render_rgb8(W, H, s0, spp, precision="f64", stats=st_a)
             out = torch.full((H, W, 3), 77, dtype=torch.uint8, device="cuda:0")
             got = ds.render_rgb8(W, H, s0, spp, precision="f64", stats=st_b, noalloc=True, out=out)
+            det = ds.render_rgb8(W, H, s0, spp, precision="f64", noalloc=True, deterministic=True)
             torch.cuda.synchronize()
-            assert torch.equal(got, want), (name, W, H)
+            for other in (want, det):  # default vs default, and default vs the reproducible mode: the same samples
+                d = (got.int() - other.int()).abs()
+                assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3, (name, W, H)
             assert st_a.tolist() == st_b.tolist() and st_a[0].item() == W * H * spp
-            assert got.float().std().item() > 1.0  # an image, not a constant
     finally:
         ds.close()
         hs.close()
@@ -43,8 +74,8 @@ def test_noalloc_rejects_frames_beyond_the_scratch(gpu):
         rc = _ffi.hip().rt_render_rgb8_noalloc(ds._h, C.byref(p), C.c_void_p(out.data_ptr()), None, None)
         assert rc == 1 and b"RT_NOALLOC_MAX_PIXELS" in _ffi.hip().rt_last_error()
         # the largest admissible frame works (1024 x 1024, 1 sample)
-        big = ds.render_rgb8(1024, 1024, 0, 1, precision="f32", noalloc=True)
-        want = ds.render_rgb8(1024, 1024, 0, 1, precision="f32")
+        big = ds.render_rgb8(1024, 1024, 0, 1, precision="f32", noalloc=True, deterministic=True)
+        want = ds.render_rgb8(1024, 1024, 0, 1, precision="f32", deterministic=True)
         assert torch.equal(big, want)
     finally:
         ds.close()

@@ -18,7 +18,9 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
+import subprocess
 import sys
 from collections import defaultdict
 
@@ -72,10 +74,31 @@ def main():
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch_upper"] + d["hbm_write_bytes_per_launch"]
         if kstat:
             d["hbm_gbs_achieved"] = d["hbm_bytes_per_launch"] / (float(kstat["AverageNs"]) * 1e-9) / 1e9
-    summary = {"source": src, "kernel": meta.get("Kernel_Name", kern), "dispatch": meta, "kernel_stats": kstat, "counters_avg_per_launch": avg, "derived": d}
+    # which build was profiled: the bench line inside the passes' logs carries the library's build id (rt_describe: "build=<hash of
+    # the device sources and flags>"); HEAD is this checkout's commit when the summary is written, "+" when the device sources in
+    # the tree are no longer the ones that were profiled
+    build = None
+    for f in sorted(glob.glob(os.path.join(src, "*.log"))):
+        m = re.search(r"build=([0-9a-f]{12})", open(f, errors="replace").read())
+        if m:
+            build = m.group(1)
+            break
+    head = None
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        sys.path.insert(0, root)
+        from importlib import import_module
+        if head and build and import_module("ray-tracing_amd._build").source_id() != build:
+            head += "+"
+    except Exception:
+        pass
+    summary = {"source": src, "build": build, "head": head, "kernel": meta.get("Kernel_Name", kern), "dispatch": meta, "kernel_stats": kstat,
+               "counters_avg_per_launch": avg, "derived": d}
     json.dump(summary, open(out + "_summary.json", "w"), indent=1)
     with open(out + "_summary.md", "w") as f:
         f.write(f"# rocprofv3 summary — {os.path.basename(out)}\n\nsource: `{src}` (tools/gpu_round.sh), kernel `{meta.get('Kernel_Name', kern)}`\n\n")
+        f.write(f"build `{build}` (hash of the device sources and flags, as the library reports it in `rt_describe`), summary written at HEAD `{head}`\n\n")
         f.write("command per pass: `rocprofv3 [--kernel-trace --stats | --pmc <counters>] --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32`\n\n")
         if kstat:
             f.write(f"kernel trace: {kstat['Calls']} launches, average {float(kstat['AverageNs'])/1e6:.3f} ms "
@@ -93,7 +116,7 @@ def main():
     if len(sys.argv) > 4:  # key "<scene>_<W>x<H>_<spp>spp_<precision>": the hardware view bench.py prints as roofline.executed / .traffic
         p = os.path.join(os.path.dirname(out) or ".", "pmc_views.json")
         rec = json.load(open(p)) if os.path.exists(p) else {}
-        view = {"from": os.path.basename(out)}
+        view = {"from": os.path.basename(out), "build": build, "head": head}
         if "hbm_bytes_per_launch" in d:
             view["hbm_bytes_per_launch"] = d["hbm_bytes_per_launch"]
         if "valu_utilization_pct" in d:
