@@ -204,9 +204,10 @@ typedef struct RtRenderParams {
  * level of the resolved image can flip.  With this flag ONE lane renders all of a pixel's samples of the launch, in
  * index order, sums them in f64 in that order and adds the rounded sum to d_accum with one plain store: the same call
  * gives the same bits on every run (and on every gfx950), and d_accum of a zeroed buffer is the reference's sum
- * rounded to f32.  Cost: the wave-level kernel without sample chunks — no block regrouping, no streaming jobs;
- * measured 0.70x (cornell_box 1024^2 @ 1024 spp per launch) to 0.95x (random_scene) of the default throughput, less
- * on small frames with few samples.  Implies RT_RENDER_NO_SORT. */
+ * rounded to f32.  Cost: the wave-level kernel without sample chunks, block regrouping or streaming jobs, and a wave
+ * is as slow as the lane with the longest paths; measured on one MI355X, f64, share of the default throughput: earth
+ * 0.88, cornell_box 1024^2 @ 1024 spp 0.66 (@ 128 spp 0.62), final_scene 0.47, random_scene 0.39.
+ * Implies RT_RENDER_NO_SORT. */
 enum RtRenderFlags { RT_RENDER_NO_SORT = 1, RT_RENDER_DETERMINISTIC = 2 };
 
 /* d_stats: 4 x uint64 counters, ADDED to by rt_render:

@@ -3,7 +3,10 @@
 A device frame equals the oracle's sample for sample except where a libm-sized difference (the device's sin / cos / atan2 / asin /
 log against glibc's, <= 2 ulp) flips a branch of ONE path — a checker sign, a Perlin floor, a refraction draw.  The frame tests used
 to allow a fixed 0.2-0.5 % of pixels to differ by any amount without looking at them.  frame_close() instead
-  * logs the observed share of pixels outside the tolerance (gpurun_out/pixel_allowance.jsonl) and holds it to `floor`,
+  * logs the observed number of pixels outside the tolerance (gpurun_out/pixel_allowance.jsonl) and holds it to `max_off` pixels
+    per frame.  MEASURED (round 3, MI355X, the whole -m gpu suite: 138 frames, 9 named scenes + ~60 generated ones, both render
+    kernels): 0 pixels outside the tolerance in every frame.  The allowance is therefore 2 PIXELS per frame (not 0.2-0.5 % of
+    them): room for a branch flip on a box whose libm results differ, nothing more,
   * and for the pixels that do differ asks the device for that pixel's samples one by one (rt_debug_sample_pixel) and requires that
     AT MOST ONE sample of the pixel departs from the oracle's by more than 1e-9 relative, and that this one sample accounts for
     the pixel's whole difference — a rare-path bug that moved many samples, or a lost / doubled sample, fails here however few
@@ -28,7 +31,7 @@ def _log(rec):
         pass
 
 
-def frame_close(tag, got, ref, ds, oc, s0, spp, rtol=2e-6, floor=0.998, seed=None, max_depth=50, max_nan_retries=64):
+def frame_close(tag, got, ref, ds, oc, s0, spp, rtol=2e-6, max_off=2, seed=None, max_depth=50, max_nan_retries=64):
     """got: device frame [H, W, 3] (f32 sums of samples [s0, s0+spp)); ref: the oracle's f64 sums.  Returns the share of pixels
     within rtol."""
     got = np.asarray(got, dtype=np.float64)
@@ -51,7 +54,7 @@ def frame_close(tag, got, ref, ds, oc, s0, spp, rtol=2e-6, floor=0.998, seed=Non
         d_samples = dev.sum(axis=0) - orc.sum(axis=0)
         scale = np.maximum(np.maximum(np.abs(ref[y, x]), np.abs(dev).sum(axis=0)), 1.0)
         assert (np.abs(d_frame - d_samples) <= 4.0 * rtol * scale).all(), f"{tag}: pixel ({x},{y}) differs by {d_frame}, its samples by {d_samples}"
-    _log({"tag": tag, "W": W, "H": H, "spp": spp, "pixels_off": int((~close).sum()), "frac_close": frac, "floor": floor,
+    _log({"tag": tag, "W": W, "H": H, "spp": spp, "pixels_off": int((~close).sum()), "frac_close": frac, "max_off": max_off,
           "samples_off_per_probed_pixel": explained})
-    assert frac >= floor, f"{tag}: only {frac:.5f} of pixels equal the oracle's (floor {floor})"
+    assert int((~close).sum()) <= max_off, f"{tag}: {int((~close).sum())} pixels differ from the oracle's frame (allowed: {max_off}, each explained by one sample)"
     return frac

@@ -18,6 +18,7 @@ import pytest
 import torch
 
 import ray_tracing_amd as rt
+from frame_check import frame_close
 from oracle_lib import DEFAULT_SEED, OracleScene, resolve as oracle_resolve
 
 pytestmark = pytest.mark.gpu
@@ -252,7 +253,7 @@ def test_persistent_kernel_sample_chunks(name, W, H, spp, scenes):
         a = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
         st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
         ds.render_into(a, 3, spp, precision="f64", stats=st, no_sort=no_sort)
-        frame_close(f"sample_chunks[{name},no_sort={no_sort}]", a.cpu().numpy(), ref, ds, oc, 3, spp, rtol=4e-6, floor=0.995)
+        frame_close(f"sample_chunks[{name},no_sort={no_sort}]", a.cpu().numpy(), ref, ds, oc, 3, spp, rtol=4e-6)
         assert st[0].item() + st[3].item() == W * H * spp
         assert abs(int(st[1]) - cnt["casts"]) <= 0.003 * cnt["casts"] + 2
         # two launches of half the samples add up to the same frame
@@ -364,7 +365,7 @@ def test_random_flat_scene_gpu_equals_oracle(seed, gpu):
             acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
             st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
             ds.render_into(acc, 0, spp, precision="f64", stats=st, no_sort=no_sort)
-            frame_close(f"flat_fuzz[{seed},no_sort={no_sort}]", acc.cpu().numpy(), ref, ds, oc, 0, spp, floor=0.995)
+            frame_close(f"flat_fuzz[{seed},no_sort={no_sort}]", acc.cpu().numpy(), ref, ds, oc, 0, spp)
             assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
@@ -393,7 +394,7 @@ def test_json_scene_fixture_gpu(fixture, gpu, golden_dir):
         acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
         st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
         ds.render_into(acc, 0, spp, precision="f64", stats=st)
-        frame_close(f"json_fixture[{fixture}]", acc.cpu().numpy(), ref_f, ds, oc, 0, spp, floor=0.995)
+        frame_close(f"json_fixture[{fixture}]", acc.cpu().numpy(), ref_f, ds, oc, 0, spp)
         assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
     finally:
         ds.close()
