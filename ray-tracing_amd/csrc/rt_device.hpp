@@ -36,7 +36,7 @@ extern "C" unsigned long long g_sim_walk_hist[64];  // walks by number of node c
 // Profiling build (-DRT_PHASE_CLOCK, tools/build_ab.py): per-wave cycle and active-lane sums per phase of the
 // wave-level render kernel, printed for a few blocks.  Slots: [i] cycles, [16+i] cycles x active lanes.
 #if defined(RT_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
-__device__ inline unsigned long long* rt_pc() { __shared__ unsigned long long pc[4][32]; return pc[threadIdx.x >> 6]; }
+__device__ inline unsigned long long* rt_pc() { __shared__ unsigned long long pc[16][32]; return pc[threadIdx.x >> 6]; }
 #define RT_PCB() unsigned long long pc_t_ = __builtin_readcyclecounter()
 #define RT_PCE(i)                                                                                        \
     do {                                                                                                 \

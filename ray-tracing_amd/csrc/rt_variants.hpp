@@ -48,10 +48,24 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
     return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
 #endif
 }
-template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
+// Lanes per block of the persistent wave kernel.  Its waves never meet at a barrier after start-up, so a variant that stages a
+// BVH table in LDS can run as ONE block per CU (BIG: 256 lanes x waves per SIMD — 768 in f64, 1024 in f32): the CU then holds one
+// copy of the node table instead of one per 256-lane block, i.e. room for 3-4x the entries.  Round 3, same box, f64: final_scene
+// (2798 entries; 3 blocks per CU hold 1184 each: 42 % of the fetches from LDS, the rest from L2) 319.5 -> 334.7 Msamples/s at
+// 1024^2 @ 64 spp; random_scene, whose 959 entries fit either way, LOSES 1-4 % (a fixed ~0.1 ms per launch and ~1 %) — so the
+// launcher takes the big block only when the scene's trees do not fit the small block's table (rt_kernels.inc: launch_variant).
+template <class T, uint32_t F, bool BIG> __device__ __host__ constexpr uint32_t wave_block() {
+    return ((F & F_BVH) && BIG) ? 256u * (uint32_t)waves_per_simd<T, F>() : 256u;
+}
+template <class T, uint32_t F> __device__ __host__ constexpr uint32_t lds_perlin_tables();
+template <class T, uint32_t F, bool BIG = false> __device__ __host__ constexpr uint32_t lds_bvh_entries() {
 #ifdef RT_LDS_BVH_ENTRIES
     return RT_LDS_BVH_ENTRIES;
 #else
+    if (wave_block<T, F, BIG>() > 256u) {
+        // one block per CU: all of the CU's 160 KB less the per-wave pixel sums (1.5 KB each), the Perlin table(s) and 2 KB to spare
+        return (163840u - wave_block<T, F, BIG>() / 64u * 1536u - lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>) - 2048u) / 32u;
+    }
     if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
     return (sizeof(T) == 4 && (F & F_NOISE)) ? 896u : 1024u;  // f32 generic: 4 blocks x (28 KB + 4.75 KB Perlin table + 6 KB)
 #endif
