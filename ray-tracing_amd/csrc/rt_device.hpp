@@ -71,6 +71,8 @@ enum : uint32_t {
     F_TEXTURED = 1u << 11,   // any non-SolidColor texture (checker / noise / image)
     F_UV = 1u << 12,         // some material needs the hit's (u,v)
     F_NOISE = 1u << 13,      // a NoiseTexture exists: the render kernels stage Perlin tables in LDS
+    F_MEDIUM_BVH = 1u << 14, // a ConstantMedium whose boundary is a BvhNode tree (no scene of scenes.rs has one): both boundary searches
+                             // are then tree walks, and the search range of a medium stays live across the walk code
     F_ALL = 0xffffffffu
 };
 template <uint32_t F> __device__ constexpr bool has(uint32_t bit) { return (F & bit) != 0; }
@@ -751,8 +753,13 @@ __device__ inline void walk_begin(const DScene<T>& sc, uint32_t geom_index, V3<T
 // Node records come from global memory (L2): the LDS copy the render kernels stage is of the device's own trees.
 // This is the EXACT EMULATION of the reference's traversal (order, box decisions in the grazing cases); the render
 // kernels run it only for the rays walk_fast could not vouch for.
+#if defined(RT_NOINLINE_REFWALK) && !defined(RT_HOST_SIM)
+#define RT_REFWALK_ATTR __attribute__((noinline))
+#else
+#define RT_REFWALK_ATTR inline
+#endif
 template <class T, uint32_t F>
-__device__ inline void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, const RayInv<T>& inv, T time) {
+__device__ RT_REFWALK_ATTR void walk_run(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T> d, const RayInv<T>& inv, T time) {
     const int n_lds = 0;
     int i = w.i;
     const int end = w.end;
@@ -1114,7 +1121,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
                     const T t = t1 + hit_distance / len;
                     any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.side = 7;
                     int first = (int)in.geom_index;  // boundary's first primitive in pre-order
-                    if (has<F>(F_BVH) && in.geom_kind != 0) {
+                    if (has<F>(F_BVH) && has<F>(F_MEDIUM_BVH) && in.geom_kind != 0) {
                         int e = sc.bvh_root_entry[in.geom_index];
                         while (sc.bvh[e].prim < 0) e++;
                         first = sc.bvh[e].prim;
@@ -1132,19 +1139,30 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
                 continue;
             }
         }
-        const int passes = med ? 2 : 1;
+        if (has<F>(F_MEDIUM) && med) {
+            // any other boundary: two searches, (-max, max) then (t1 + 0.0001, max) (src/objects.rs:529-536).  Without F_MEDIUM_BVH the
+            // boundary is one primitive and the walk code below is not part of this branch (nor its state live across it).
+            T tb = T(0);
+            int found = 0;
 #pragma nounroll
-        for (int pass = 0; pass < passes; pass++) {
-            const T lo = med ? (pass == 0 ? -Lim<T>::max() : ta + T(0.0001)) : t_min;
-            const T hi = med ? Lim<T>::max() : closest;
-            T t = hi; int prim = -1, side = 0;
-            const bool h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, lo, hi, t, prim, side);
-            if (!med) {
-                if (h) { any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side; }
-            } else if (has<F>(F_MEDIUM)) {
+            for (int pass = 0; pass < 2; pass++) {
+                const T lo = pass == 0 ? -Lim<T>::max() : ta + T(0.0001);
+                T t = Lim<T>::max(); int prim = -1, side = 0;
+                bool h;
+                if (has<F>(F_MEDIUM_BVH)) h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, lo, Lim<T>::max(), t, prim, side);
+                else h = prim_hit<T, F>(sc.prims[in.geom_index], o, d, inv, ray.time, lo, Lim<T>::max(), t, side);
                 if (!h) break;
-                if (pass == 0) { ta = t; continue; }
-                medium_event(t);
+                found++;
+                if (pass == 0) ta = t; else tb = t;
+            }
+            if (found == 2) medium_event(tb);
+            RT_PCE(7);
+            continue;
+        }
+        {
+            T t = closest; int prim = -1, side = 0;
+            if (geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, t_min, closest, t, prim, side)) {
+                any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side;
             }
         }
     }
@@ -1152,11 +1170,29 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
 }
 
 // src/objects.rs:208-215
+// The f64 form is a real CALL (noinline), not inlined code: ocml's f64 atan2 / asin want ~60 registers, and inlined at the end of the
+// cast — where the whole path state is live — they were what the f64 BVH kernels spilled for (round 3, scratch per lane with the call:
+// spheres + BVH 248 -> 16 B, generic 328 -> 96 B, flat spheres 230 -> 164 registers; final_scene +1.5 %, random_scene +0.4 %, earth
+// -0.3 %).  The call is only made by waves in which some lane's material reads (u,v) (an image or uv-checker texture); in f32 the
+// functions are small and stay inline (the call measured -1..-2 % there).
+template <class T> struct UV { T u, v; };
+template <class T> __device__ inline UV<T> sphere_uv_body(T px, T py, T pz) {
+    T phi = ratan2(pz, px);
+    T theta = rasin(py);
+    UV<T> r;
+    r.u = T(1) - (phi + Consts<T>::pi()) / (T(2) * Consts<T>::pi());
+    r.v = (theta + Consts<T>::pi() / T(2)) / Consts<T>::pi();
+    return r;
+}
+#if !defined(RT_HOST_SIM) && !defined(RT_INLINE_UV)
+__device__ __attribute__((noinline)) inline UV<double> sphere_uv_call(double px, double py, double pz) { return sphere_uv_body<double>(px, py, pz); }
+#else
+__device__ inline UV<double> sphere_uv_call(double px, double py, double pz) { return sphere_uv_body<double>(px, py, pz); }
+#endif
+__device__ inline UV<float> sphere_uv_call(float px, float py, float pz) { return sphere_uv_body<float>(px, py, pz); }
 template <class T> __device__ inline void sphere_uv(V3<T> p, T& u, T& v) {
-    T phi = ratan2(p.z, p.x);
-    T theta = rasin(p.y);
-    u = T(1) - (phi + Consts<T>::pi()) / (T(2) * Consts<T>::pi());
-    v = (theta + Consts<T>::pi() / T(2)) / Consts<T>::pi();
+    const UV<T> r = sphere_uv_call(p.x, p.y, p.z);
+    u = r.u; v = r.v;
 }
 
 template <class T> struct HitRecord { T t; V3<T> p, normal; T u, v; };

@@ -370,6 +370,7 @@ inline uint32_t scene_features(const RtSceneDesc* d) {
         for (uint32_t i = 0; i < n; i++) {
             if (world && ins[i].geom_kind == RT_GEOM_BVH) f |= F_BVH;
             if (world && ins[i].is_medium) f |= F_MEDIUM;
+            if (world && ins[i].is_medium && ins[i].geom_kind == RT_GEOM_BVH) f |= F_MEDIUM_BVH;
             if (ins[i].xform_count) f |= F_XFORM;
         }
     };

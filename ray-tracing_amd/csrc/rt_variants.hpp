@@ -9,7 +9,10 @@ constexpr uint32_t V_SMOKE = V_CORNELL | F_MEDIUM;                              
 constexpr uint32_t V_SPHERES = F_BVH | F_SPHERE | F_MOVING | F_METAL | F_DIELECTRIC | F_TEXTURED | F_UV;   // random_scene, earth, checker spheres
 constexpr uint32_t V_SPHERES_FLAT = V_SPHERES & ~F_BVH;                                                      // earth, two_checker_spheres (no LDS node table)
 constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                                               // two_perlin_spheres
-constexpr uint32_t V_FINAL = 0x3fffu & ~F_FROSTED;  // final_scene: every feature but FrostedDielectric (only random_scene_light has one)
+#ifndef RT_V_FINAL_MASK
+#define RT_V_FINAL_MASK (0x3fffu & ~F_FROSTED)
+#endif
+constexpr uint32_t V_FINAL = RT_V_FINAL_MASK;  // final_scene: every feature but FrostedDielectric (only random_scene_light has one)
 
 // Register budget of the persistent render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
 // SIMD: 2 -> 256, 3 -> 168, 4 -> 128), and the LDS budget of the staged BVH head (32-byte entries), sized so that
@@ -41,11 +44,17 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
 #else
+#ifndef RT_WPS_SPHERES_BVH
+#define RT_WPS_SPHERES_BVH 4
+#endif
+#ifndef RT_WPS_FLAT_UV
+#define RT_WPS_FLAT_UV 3
+#endif
     if (F & F_BVH) {
         if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? 3 : 4;  // the generic variant (final_scene)
-        return sizeof(T) == 8 ? 3 : 4;                                                      // spheres + BVH (random_scene)
+        return sizeof(T) == 8 ? RT_WPS_SPHERES_BVH : 4;                                     // spheres + BVH (random_scene)
     }
-    return sizeof(T) == 8 ? ((F & F_UV) ? 2 : ((F & F_NOISE) ? 4 : 3)) : 4;
+    return sizeof(T) == 8 ? ((F & F_UV) ? RT_WPS_FLAT_UV : ((F & F_NOISE) ? 4 : 3)) : 4;
 #endif
 }
 // Lanes per block of the persistent wave kernel.  Its waves never meet at a barrier after start-up, so a variant that stages a
