@@ -153,15 +153,72 @@ template <> struct Lim<float> { static __device__ constexpr float max() { return
 
 __device__ inline double sqrt_r(double x) { return ::sqrt(x); }
 __device__ inline float sqrt_r(float x) { return ::sqrtf(x); }
+#if defined(RT_CALL_SIN) && !defined(RT_HOST_SIM)
+__device__ __attribute__((noinline)) inline double rsin(double x) { return ::sin(x); }
+#else
 __device__ inline double rsin(double x) { return ::sin(x); }
+#endif
 __device__ inline float rsin(float x) { return ::sinf(x); }
 __device__ inline void rsincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+// sin and cos of an angle KNOWN to lie in [0, 2 pi] (the azimuth 2 pi r1 of a sampled direction, vec3.rs:231-248).  ocml's f64 sincos
+// is a general routine (argument reduction for any magnitude, ~75 executed instructions, ~60 registers: inlined into the Lambertian
+// bounce it was what the block-sorted Cornell kernel spilled for).  With the range known the reduction is one Cody-Waite step
+// (fdlibm's __ieee754_rem_pio2 medium path: k <= 4, so k * pio2_1 is exact) followed by fdlibm's __kernel_sin / __kernel_cos
+// polynomials (FreeBSD msun's branch-free form of the latter).  Checked against quad precision on 2e7 arguments (uniform and next to
+// the multiples of pi/2): absolute error <= 8.7e-17, <= 0.78 ulp wherever |result| > 1e-6 (glibc: 0.56) — the same class of
+// "<= 1 ulp libm" difference the device's ocml already had against the oracle's glibc.  The CPU build of these templates
+// (tests/hostsim) keeps ::sincos.
+struct SinCos { double s, c; };
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__) || defined(RT_OCML_SINCOS)
+__device__ inline SinCos sincos_0_2pi(double x) { SinCos r; ::sincos(x, &r.s, &r.c); return r; }
+#else
+#ifdef RT_SINCOS_INLINE
+__device__ inline SinCos sincos_0_2pi(double x) {
+#else
+__device__ __attribute__((noinline)) inline SinCos sincos_0_2pi(double x) {
+#endif
+    double s, c;
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const int k = (int)(x * two_over_pi + 0.5);
+    const double fn = (double)k;
+    const double r = x - fn * pio2_1;
+    const double w = fn * pio2_1t;
+    const double y0 = r - w;
+    const double y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y0;
+    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+    const double sn = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double w2 = z * z;
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, C3, C2), C1) + (w2 * w2) * __builtin_fma(z, __builtin_fma(z, C6, C5), C4);
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    const double cs = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    const bool odd = (k & 1) != 0;
+    const double a = odd ? cs : sn, b = odd ? sn : cs;
+    s = (k & 2) ? -a : a;
+    c = ((k + 1) & 2) ? -b : b;
+    SinCos out; out.s = s; out.c = c;
+    return out;
+}
+#endif
+__device__ inline void rsincos_0_2pi(double x, double& s, double& c) { const SinCos r = sincos_0_2pi(x); s = r.s; c = r.c; }
+__device__ inline void rsincos_0_2pi(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
 __device__ inline void rsincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
 __device__ inline double ratan2(double y, double x) { return ::atan2(y, x); }
 __device__ inline float ratan2(float y, float x) { return ::atan2f(y, x); }
 __device__ inline double rasin(double x) { return ::asin(x); }
 __device__ inline float rasin(float x) { return ::asinf(x); }
+#if defined(RT_CALL_LOG) && !defined(RT_HOST_SIM)
+__device__ __attribute__((noinline)) inline double rlog(double x) { return ::log(x); }
+#else
 __device__ inline double rlog(double x) { return ::log(x); }
+#endif
 __device__ inline float rlog(float x) { return ::logf(x); }
 __device__ inline double rfloor(double x) { return ::floor(x); }
 __device__ inline float rfloor(float x) { return ::floorf(x); }

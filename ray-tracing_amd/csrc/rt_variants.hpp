@@ -51,7 +51,10 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
 #define RT_WPS_FLAT_UV 3
 #endif
     if (F & F_BVH) {
-        if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? 3 : 4;  // the generic variant (final_scene)
+#ifndef RT_WPS_GENERIC
+#define RT_WPS_GENERIC 3
+#endif
+        if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? RT_WPS_GENERIC : 4;  // the generic variant (final_scene)
         return sizeof(T) == 8 ? RT_WPS_SPHERES_BVH : 4;                                     // spheres + BVH (random_scene)
     }
     return sizeof(T) == 8 ? ((F & F_UV) ? RT_WPS_FLAT_UV : ((F & F_NOISE) ? 4 : 3)) : 4;
@@ -75,7 +78,7 @@ template <class T, uint32_t F, bool BIG = false> __device__ __host__ constexpr u
         // one block per CU: all of the CU's 160 KB less the per-wave pixel sums (1.5 KB each), the Perlin table(s) and 2 KB to spare
         return (163840u - wave_block<T, F, BIG>() / 64u * 1536u - lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>) - 2048u) / 32u;
     }
-    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
+    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return RT_WPS_GENERIC == 4 ? 864u : 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
     return (sizeof(T) == 4 && (F & F_NOISE)) ? 896u : 1024u;  // f32 generic: 4 blocks x (28 KB + 4.75 KB Perlin table + 6 KB)
 #endif
 }
@@ -105,7 +108,9 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
     // f64 with media (cornell_smoke): at 4 waves the persistent-block kernel spills 204 B per lane, 53 MB of scratch for the resident
     // lanes, more than the L2 holds (29.8 GB per 31 ms launch went to the memory side); at 3 waves 24 B: +2 % (2255 -> 2298 Msamples/s
     // at 1024 spp per launch, 2170 -> 2218 at 64).  Without media 3 waves lose 12 % (cornell_box: spills are 112 B there and fit).
-    constexpr uint32_t most = sizeof(T) == 8 ? ((F & F_MEDIUM) ? 3u : 4u) : 7u;
+    // ROUND 3: with the media search restructured (F_MEDIUM_BVH) and the range-limited sincos as a call the media variant spills 64 B at
+    // 4 waves (0 at 3): 4 waves measure cornell_smoke 2484 -> 2754 Msamples/s @ 64 spp per launch, 2574 -> 2885 @ 1024.
+    constexpr uint32_t most = sizeof(T) == 8 ? 4u : 7u;
 #endif
     // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
     // blocks per CU that LDS admits x waves per block / 4 SIMDs
