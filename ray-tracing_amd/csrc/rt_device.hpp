@@ -739,6 +739,13 @@ __device__ inline int aabb_classify_f(const float* mn, const float* mx, const Ra
     return in_hi - in_lo > 0.0f ? 1 : (out_hi - out_lo < 0.0f ? 0 : 2);
 }
 
+__device__ inline float canonical(float x) {
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__)
+    return x;
+#else
+    return __builtin_canonicalizef(x);
+#endif
+}
 // Entry i of the table staged in LDS.  The generic pointer is narrowed to the LDS address space by hand
 // (its low 32 bits are the LDS offset): the optimiser cannot infer it through DScene, and a flat load
 // would wait on both memory counters.
@@ -909,6 +916,7 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
     int ref_parent = 0;
     // per axis the bound the ray meets first: near = min for a positive direction (a bad ray never culls: the pick is irrelevant)
     const bool px = w.r.ix >= 0.0f, py = w.r.iy >= 0.0f, pz = w.r.iz >= 0.0f;
+    const float tmin_lo_c = canonical(w.r.tmin_lo);  // (known canonical: fmaxf below needs no per-step quieting instruction for it)
 #if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
     const unsigned long long sim_n0 = g_sim_counters[0];
 #endif
@@ -923,13 +931,25 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
             if (i < n_lds) e = lds_entry(sc.bvh_lds, i); else e = sc.fast_lite[i];
             prim = e.prim;
             // outer interval only: lo - e on the near bounds, hi + e on the far ones (see aabb_classify_f)
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__) || !defined(RT_PK_FMA)
             const float lox = fmaf(px ? e.mn[0] : e.mx[0], w.r.ix, w.r.kmx), hix = fmaf(px ? e.mx[0] : e.mn[0], w.r.ix, w.r.kpx);
             const float loy = fmaf(py ? e.mn[1] : e.mx[1], w.r.iy, w.r.kmy), hiy = fmaf(py ? e.mx[1] : e.mn[1], w.r.iy, w.r.kpy);
             const float loz = fmaf(pz ? e.mn[2] : e.mx[2], w.r.iz, w.r.kmz), hiz = fmaf(pz ? e.mx[2] : e.mn[2], w.r.iz, w.r.kpz);
-            const float out_lo = fmaxf(fmaxf(lox, loy), fmaxf(loz, w.r.tmin_lo));
+#else
+            // EXPERIMENT (-DRT_PK_FMA, measured and not adopted): the (near, far) pair of an axis through ONE packed multiply-add
+            // (v_pk_fma_f32): 3 instead of 6 of the node step's ~30 vector instructions, but the operand pairs cost registers —
+            // spheres + BVH spills 160 -> 208 B, random_scene 2590 -> 2417 Msamples/s
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 tx = __builtin_elementwise_fma(f32x2{px ? e.mn[0] : e.mx[0], px ? e.mx[0] : e.mn[0]}, f32x2{w.r.ix, w.r.ix}, f32x2{w.r.kmx, w.r.kpx});
+            const f32x2 ty = __builtin_elementwise_fma(f32x2{py ? e.mn[1] : e.mx[1], py ? e.mx[1] : e.mn[1]}, f32x2{w.r.iy, w.r.iy}, f32x2{w.r.kmy, w.r.kpy});
+            const f32x2 tz = __builtin_elementwise_fma(f32x2{pz ? e.mn[2] : e.mx[2], pz ? e.mx[2] : e.mn[2]}, f32x2{w.r.iz, w.r.iz}, f32x2{w.r.kmz, w.r.kpz});
+            const float lox = tx.x, hix = tx.y, loy = ty.x, hiy = ty.y, loz = tz.x, hiz = tz.y;
+#endif
+            const float out_lo = fmaxf(fmaxf(lox, loy), fmaxf(loz, tmin_lo_c));
             const float out_hi = fminf(fminf(hix, hiy), fminf(hiz, tmax_hi));
             const bool miss = !w.r.bad && (out_hi - out_lo < 0.0f);
             RT_SIM_COUNT(0);
+#ifdef RT_WALK_NESTED_IFS
             if (prim >= 0) {
                 if (!miss || !w.leaf_cull) break;  // a leaf that cannot be ruled out is tested
                 RT_SIM_COUNT(4);
@@ -937,6 +957,16 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
                 continue;
             }
             i = miss ? e.skip : i + 1;
+#else
+            // one exit test and one select per step: a leaf that cannot be ruled out is tested; a culled leaf and an entered node go on
+            // to the next entry, a skipped node to the end of its subtree
+            const bool leaf = prim >= 0;
+            if (leaf & !(miss & w.leaf_cull)) break;
+#if defined(RT_HOST_SIM) && defined(RT_SIM_COUNTERS)
+            if (leaf) RT_SIM_COUNT(4);
+#endif
+            i = (miss & !leaf) ? e.skip : i + 1;
+#endif
         }
         RT_PCE(2);
         if (i == end) break;

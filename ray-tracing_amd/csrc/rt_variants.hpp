@@ -76,7 +76,11 @@ template <class T, uint32_t F, bool BIG = false> __device__ __host__ constexpr u
 #else
     if (wave_block<T, F, BIG>() > 256u) {
         // one block per CU: all of the CU's 160 KB less the per-wave pixel sums (1.5 KB each), the Perlin table(s) and 2 KB to spare
-        return (163840u - wave_block<T, F, BIG>() / 64u * 1536u - lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>) - 2048u) / 32u;
+        return (163840u - wave_block<T, F, BIG>() / 64u * 1536u - lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>) - 2048u
+#ifdef RT_PHASE_CLOCK
+                - 4096u  // (the profiling build's per-wave clock slots)
+#endif
+                ) / 32u;
     }
     if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return RT_WPS_GENERIC == 4 ? 864u : 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
     return (sizeof(T) == 4 && (F & F_NOISE)) ? 896u : 1024u;  // f32 generic: 4 blocks x (28 KB + 4.75 KB Perlin table + 6 KB)
