@@ -246,7 +246,10 @@ struct SahBox {
     }
 };
 struct SahLeaf { int32_t prim, ref_parent; double mn[3], mx[3], c[3]; };
-inline int32_t sah_build(std::vector<SahLeaf>& leaves, size_t lo, size_t hi, SahTree& out, int depth) {
+// eye: the camera's origin in the tree's object space.  The threaded layout visits a node's children in ONE fixed order for every ray;
+// the child nearer to the eye goes first, so that camera rays (38 % of random_scene's casts) find their closest hit early and cull
+// the rest of the tree with it.  Any order gives the same hit (rt_device.hpp: walk_fast).
+inline int32_t sah_build(std::vector<SahLeaf>& leaves, size_t lo, size_t hi, SahTree& out, int depth, const double* eye) {
     // leaves[lo, hi), hi - lo >= 2; returns the node index
     const int32_t me = out.add();
     SahBox all; all.reset();
@@ -317,10 +320,28 @@ inline int32_t sah_build(std::vector<SahLeaf>& leaves, size_t lo, size_t hi, Sah
     if (best_axis < 0) {  // all centroids equal / too deep: median split in the given order
         mid = lo + n / 2;
     }
+#ifndef RT_SAH_NO_EYE_ORDER
+    if (eye) {
+        auto dist2 = [&](size_t a, size_t b) {
+            SahBox bx; bx.reset();
+            for (size_t i = a; i < b; i++) bx.grow(leaves[i].mn, leaves[i].mx);
+            double s2 = 0.0;
+            for (int k = 0; k < 3; k++) {
+                const double dk = eye[k] < bx.mn[k] ? bx.mn[k] - eye[k] : (eye[k] > bx.mx[k] ? eye[k] - bx.mx[k] : 0.0);
+                s2 += dk * dk;
+            }
+            return s2;
+        };
+        if (dist2(mid, hi) < dist2(lo, mid)) {  // (NaN compares false: order kept)
+            std::rotate(leaves.begin() + lo, leaves.begin() + mid, leaves.begin() + hi);
+            mid = lo + (hi - mid);
+        }
+    }
+#endif
     // children in pre-order: node, left subtree, right subtree (RtBvh convention)
     // (a leaf child is the complement of its final position in `leaves`: ranges of one element do not move any more)
-    const int32_t l = (mid - lo == 1) ? ~(int32_t)lo : sah_build(leaves, lo, mid, out, depth + 1);
-    const int32_t r = (hi - mid == 1) ? ~(int32_t)mid : sah_build(leaves, mid, hi, out, depth + 1);
+    const int32_t l = (mid - lo == 1) ? ~(int32_t)lo : sah_build(leaves, lo, mid, out, depth + 1, eye);
+    const int32_t r = (hi - mid == 1) ? ~(int32_t)mid : sah_build(leaves, mid, hi, out, depth + 1, eye);
     out.left[me] = l; out.right[me] = r;
     return me;
 }
@@ -499,7 +520,14 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
                     all_leaves.push_back(l);
                 }
                 // (a tree's root is an internal node with two children: >= 2 leaves)
-                roots.push_back({ref_root, sah_build(all_leaves, first, all_leaves.size(), sah, 0)});
+                // the camera's origin in this instance's object space (transforms.rs:15-17, 90-97: outermost wrapper first)
+                double eye[3] = {d->camera.origin[0], d->camera.origin[1], d->camera.origin[2]};
+                for (uint32_t j = 0; j < ins[i].xform_count; j++) {
+                    const RtXform& x = d->xforms[ins[i].xform_begin + j];
+                    if (x.kind == RT_XFORM_TRANSLATE) { for (int k = 0; k < 3; k++) eye[k] -= x.v[k]; }
+                    else { const double sn = x.v[0], cs = x.v[1], ex = eye[0], ez = eye[2]; eye[0] = cs * ex - sn * ez; eye[2] = sn * ex + cs * ez; }
+                }
+                roots.push_back({ref_root, sah_build(all_leaves, first, all_leaves.size(), sah, 0, eye)});
             }
         };
         build_for(d->world, d->n_world);
