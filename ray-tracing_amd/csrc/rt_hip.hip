@@ -92,6 +92,7 @@ int build_device_scene(RtScene* sc, const RtSceneDesc* d, const rt::DImage* d_im
     if ((rc = upload(sc, h.bvh_lite, &out.bvh_lite))) return rc;
     if ((rc = upload(sc, h.fast_lite, &out.fast_lite))) return rc;
     if ((rc = upload(sc, h.fast_root_entry, &out.fast_root_entry))) return rc;
+    if ((rc = upload(sc, h.world_order, &out.world_order))) return rc;
     out.images = d_images;
     return RT_OK;
 }

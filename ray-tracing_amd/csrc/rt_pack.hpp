@@ -27,6 +27,7 @@ template <class T> struct PackedScene {
     std::vector<DBvhLite> bvh_lite;
     std::vector<DBvhLite> fast_lite;      // the device's own trees over the same leaves (SAH), threaded
     std::vector<int32_t> fast_root_entry;
+    std::vector<uint32_t> world_order;    // DScene::world_order (identity beyond the zone)
     DScene<T> view;  // scalars filled by pack_scene; pointers by whoever owns the memory
 };
 
@@ -615,6 +616,20 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
     out.perlin_lds = nullptr;
     out.tex_cache = nullptr;
     out.n_world = d->n_world;
+    {   // the zone: leading run of the world list before its first medium; plain primitives are tested first, trees last (stable)
+        uint32_t nz = 0;
+        while (nz < d->n_world && !d->world[nz].is_medium) nz++;
+        h.world_order.clear();
+        for (uint32_t i = 0; i < nz; i++) if (d->world[i].geom_kind != RT_GEOM_BVH) h.world_order.push_back(i);
+        for (uint32_t i = 0; i < nz; i++) if (d->world[i].geom_kind == RT_GEOM_BVH) h.world_order.push_back(i);
+        bool identity = true;
+        for (uint32_t i = 0; i < nz; i++) identity &= h.world_order[i] == i;
+        for (uint32_t i = nz; i < d->n_world; i++) h.world_order.push_back(i);
+#ifdef RT_NO_ZONE_ORDER
+        identity = true;
+#endif
+        out.n_zone = identity ? 0u : nz;
+    }
     out.n_materials = d->n_materials;
     out.n_lights = d->n_lights;
     for (int k = 0; k < 3; k++) out.background[k] = (T)d->background[k];

@@ -141,6 +141,61 @@ def tie_scene(seed):
     return fs
 
 
+def cross_tie_scene(seed):
+    """Equal hit distances ACROSS world-list entries (rt_device.hpp: world_hit scans the leading run of the list with the plain
+    primitives first and the trees last, and must notice when that order could decide): the leaves of a tree again as plain
+    world objects — the same sphere (strict comparison: the EARLIER list entry keeps the hit), the same cuboid, a rectangle in
+    a cuboid's face (inclusive: the LATER entry takes it) — placed BEFORE and AFTER the tree in the list, with other materials
+    so that the winner shows in the id and in the radiance.  Odd seeds put a second tree and a medium behind the first run."""
+    rng = random.Random(7000 + seed)
+    fs = F.FlatScene()
+    fs.background = [0.6, 0.7, 0.9]
+
+    def m(i):
+        return fs.material(F.LAMBERTIAN, texture=fs.solid(0.15 + 0.06 * (i % 13), 0.85 - 0.05 * (i % 11), 0.25 + 0.05 * (i % 7)))
+
+    k = 0
+    spheres, boxes = [], []
+    for _ in range(rng.randrange(4, 8)):
+        c = [float(rng.randrange(-6, 7)), float(rng.randrange(1, 6)), float(rng.randrange(-6, 7))]
+        spheres.append((c, float(rng.choice([1, 1, 2]))))
+    for _ in range(rng.randrange(3, 6)):
+        lo = [float(rng.randrange(-7, 6)), 0.0, float(rng.randrange(-7, 6))]
+        boxes.append((lo, [lo[0] + float(rng.choice([1, 2])), float(rng.randrange(1, 4)), lo[2] + float(rng.choice([1, 2]))]))
+    leaves = []
+    for c, r in spheres:
+        leaves.append(fs.sphere(c, r, m(k))); k += 1
+    for lo, hi in boxes:
+        leaves.append(fs.cuboid(lo, hi, m(k))); k += 1
+    rng.shuffle(leaves)
+    before, after = [], []
+    for c, r in spheres:
+        if rng.random() < 0.7:
+            (before if rng.random() < 0.5 else after).append(fs.sphere(c, r, m(k))); k += 1
+    for lo, hi in boxes:
+        roll = rng.random()
+        dst = before if rng.random() < 0.5 else after
+        if roll < 0.4:
+            dst.append(fs.cuboid(lo, hi, m(k))); k += 1
+        elif roll < 0.8:  # its top face as a rectangle of its own (XZ at y = hi.y)
+            dst.append(fs.rect(1, lo[0], hi[0], lo[2], hi[2], hi[1], 1.0, m(k))); k += 1
+    for p in before:
+        fs.add_world(p)
+    fs.add_world(fs.build_bvh(leaves, rng), bvh=True)
+    for p in after:
+        fs.add_world(p)
+    fs.add_world(fs.rect(1, -30, 30, -30, 30, 0.0, 1.0, m(k)))  # the plane of the cuboids' bottoms (equal to their -y faces)
+    k += 1
+    if seed % 2:
+        fog = fs.material(F.ISOTROPIC, texture=fs.solid(0.8, 0.8, 0.8))
+        fs.add_world(fs.sphere([0.0, 3.0, 0.0], 9.0, m(k)), medium=(0.05, fog))
+        more = [fs.sphere([float(rng.randrange(-6, 7)), float(rng.randrange(6, 9)), float(rng.randrange(-6, 7))], 1.0, m(k + 1 + i)) for i in range(4)]
+        fs.add_world(fs.build_bvh(more, rng), bvh=True)
+        fs.add_world(fs.sphere(spheres[0][0], spheres[0][1], m(k + 6)))  # the first tree's sphere once more, behind the medium
+    fs.camera([0.0, 4.0, 24.0], [0.0, 2.0, 0.0], [0, 1, 0], 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return fs
+
+
 def nan_scene():
     """A scene whose diffuse bounces all come out NaN: the light LIST holds a sphere that encloses the whole scene, and
     Sphere::pdf_value from inside a sphere takes the square root of a negative number (src/objects.rs:126-137).  Samples that

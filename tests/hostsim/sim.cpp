@@ -22,7 +22,7 @@ template <class T> struct Side {
         v.xforms = p.xforms.data(); v.world = p.world.data(); v.lights = p.lights.data(); v.bvh = p.bvh.data();
         v.bvh_root_entry = p.bvh_root_entry.data(); v.images = images;
         v.bvh_lite = p.bvh_lite.data();
-        v.fast_lite = p.fast_lite.data(); v.fast_root_entry = p.fast_root_entry.data();
+        v.fast_lite = p.fast_lite.data(); v.fast_root_entry = p.fast_root_entry.data(); v.world_order = p.world_order.data();
         // exercise both sources of node records: the first half "staged" (a second copy), the rest "global"
         lds_copy.assign(p.fast_lite.begin(), p.fast_lite.begin() + p.fast_lite.size() / 2);
         v.bvh_lds = lds_copy.data(); v.n_bvh_lds = (uint32_t)lds_copy.size();

@@ -12,7 +12,7 @@ import pytest
 import ray_tracing_amd as rt
 from ray_tracing_amd import flat
 from oracle_lib import OracleScene
-from flat_fuzz import extreme_scene, far_scene, instancing_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
+from flat_fuzz import cross_tie_scene, extreme_scene, far_scene, instancing_scene, medium_scene, nan_scene, odd_lights_scene, pile_scene, random_scene, texture_scene, tie_scene
 from test_hostsim import SimScene, sim, RAD_RTOL  # noqa: F401  (sim is a fixture)
 
 REF_JSON = "/root/reference/codegen/data/scene_10.json"
@@ -66,6 +66,25 @@ def test_tie_scene_sim_equals_oracle(sim, seed):
             assert np.array_equal(ts, ot)
     got, casts = sc.render(21, 15, 0, 3)
     ref, cnt = oc.render(21, 15, 0, 3, threads=4)
+    assert casts == cnt["casts"], (seed, casts, cnt["casts"])
+    assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_cross_tie_scene_sim_equals_oracle(sim, seed):
+    # equal hit distances ACROSS world-list entries: the device tests the plain primitives of the list's first run before its trees
+    # (rt_device.hpp: world_hit) and must scan in list order again wherever that order could decide
+    host = rt.FlatHostScene(cross_tie_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    sc = SimScene.from_host(sim, host)
+    for (W, H) in ((41, 31), (64, 48)):
+        for generic in (False, True):
+            ids, ts = sc.primary(W, H, 0.25, 0.5, "f64", generic)
+            oi, ot = oc.trace_primary(W, H, 0.25, 0.5)
+            assert np.array_equal(ids, oi), (seed, W, generic, int((ids != oi).sum()))
+            assert np.array_equal(ts, ot)
+    got, casts = sc.render(24, 18, 0, 3)
+    ref, cnt = oc.render(24, 18, 0, 3, threads=4)
     assert casts == cnt["casts"], (seed, casts, cnt["casts"])
     assert np.allclose(got, ref, rtol=RAD_RTOL, atol=0, equal_nan=True)
 

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import ray_tracing_amd as rt
+from frame_check import frame_close
 from oracle_lib import OracleScene
 from ray_tracing_amd import _ffi
 
@@ -94,3 +95,27 @@ def test_unknown_render_flags_are_rejected(scenes):
     p = _ffi.RtRenderParams(16, 16, 0, 1, 50, 64, 1, _ffi.RT_F64, 4)
     assert _ffi.hip().rt_render(ds._h, C.byref(p), C.c_void_p(acc.data_ptr()), None, None) == 1
     assert b"flags" in _ffi.hip().rt_last_error()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cross_tie_scene_gpu_equals_oracle(seed, gpu):
+    # tests/flat_fuzz.py: cross_tie_scene — the leaves of a tree again as plain world objects before and after it in the list: equal
+    # distances across list entries, which the reordered world scan (primitives first, trees last) must resolve as the list order does
+    from flat_fuzz import cross_tie_scene
+    host = rt.FlatHostScene(cross_tie_scene(seed))
+    oc = OracleScene.from_desc(host.desc_ptr)
+    ds = rt.DeviceScene(host, 0)
+    try:
+        for (W, H) in ((41, 31), (96, 72)):
+            ids, ts = ds.trace_primary(W, H, 0.25, 0.5, "f64")
+            oi, ot = oc.trace_primary(W, H, 0.25, 0.5)
+            assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(ts.cpu().numpy(), ot), (seed, W)
+        W, H, spp = 48, 36, 4
+        ref, cnt = oc.render(W, H, 0, spp, threads=8)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        ds.render_into(acc, 0, spp, precision="f64", stats=st)
+        frame_close(f"cross_tie[{seed}]", acc.cpu().numpy(), ref, ds, oc, 0, spp)
+        assert abs(int(st[1]) - cnt["casts"]) <= 0.005 * cnt["casts"] + 2
+    finally:
+        ds.close()
