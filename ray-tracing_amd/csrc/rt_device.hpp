@@ -159,7 +159,12 @@ template <> struct Lim<float> { static __device__ constexpr float max() { return
 
 __device__ inline double sqrt_r(double x) { return ::sqrt(x); }
 __device__ inline float sqrt_r(float x) { return ::sqrtf(x); }
-#if defined(RT_CALL_SIN) && !defined(RT_HOST_SIM)
+// ocml's general f64 routines (sin with its large-argument reduction, log; atan2 / asin in sphere_uv_call) are real CALLS in the f64
+// kernels, not inlined code: each wants ~60 registers, and inlined into shading code where the whole path state is live they were
+// what the f64 kernels spilled for.  Round 3, sin (checker and noise textures) as a call: noise variant 112 -> 16 B of scratch per
+// lane, spheres + BVH 160 -> 80 B; two_perlin_spheres 4800 -> 5640 Msamples/s, final_scene 477 -> 517, random_scene 2675 -> 2755.
+// log (ConstantMedium's free-flight distance): generic variant 96 -> 48 B, +0.3 .. 0.6 %.  (-DRT_INLINE_LIBM: the inlined form.)
+#if !defined(RT_INLINE_LIBM) && !defined(RT_HOST_SIM)
 __device__ __attribute__((noinline)) inline double rsin(double x) { return ::sin(x); }
 #else
 __device__ inline double rsin(double x) { return ::sin(x); }
@@ -220,7 +225,7 @@ __device__ inline double ratan2(double y, double x) { return ::atan2(y, x); }
 __device__ inline float ratan2(float y, float x) { return ::atan2f(y, x); }
 __device__ inline double rasin(double x) { return ::asin(x); }
 __device__ inline float rasin(float x) { return ::asinf(x); }
-#if defined(RT_CALL_LOG) && !defined(RT_HOST_SIM)
+#if !defined(RT_INLINE_LIBM) && !defined(RT_HOST_SIM)
 __device__ __attribute__((noinline)) inline double rlog(double x) { return ::log(x); }
 #else
 __device__ inline double rlog(double x) { return ::log(x); }

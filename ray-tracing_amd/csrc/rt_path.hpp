@@ -163,10 +163,8 @@ __device__ inline void lambertian_sample(const DScene<T>& sc, const HitRecord<T>
         const T s = sqrt_r(cone ? T(1) - z * z : r2);
         const T phi = T(2) * Consts<T>::pi() * r1;
         T sn, cs;
-        // phi = 2 pi r1, r1 in [0, 1): the range-limited routine (a call), except in the generic BVH variant, where ocml's inlined
-        // sincos measured 2 % faster (final_scene 420 against 412 Msamples/s; cornell_box +2.6 %, random_scene +3 % with the call)
-        if (has<F>(F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) != 0) rsincos(phi, sn, cs);
-        else rsincos_0_2pi(phi, sn, cs);
+        // phi = 2 pi r1, r1 in [0, 1): the range-limited routine, a call (rt_device.hpp: sincos_0_2pi)
+        rsincos_0_2pi(phi, sn, cs);
         const T x = cs * s, y = sn * s;
         const V3<T> lobe = tu * x + tv * y + w_f * z;  // ONB::local, pdf.rs:19-24
         dir = mode == 2 ? local_pt : lobe;

@@ -48,11 +48,11 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
 #define RT_WPS_SPHERES_BVH 4
 #endif
 #ifndef RT_WPS_FLAT_UV
-#define RT_WPS_FLAT_UV 3
+#define RT_WPS_FLAT_UV 4
 #endif
     if (F & F_BVH) {
 #ifndef RT_WPS_GENERIC
-#define RT_WPS_GENERIC 3
+#define RT_WPS_GENERIC 4
 #endif
         if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? RT_WPS_GENERIC : 4;  // the generic variant (final_scene)
         return sizeof(T) == 8 ? RT_WPS_SPHERES_BVH : 4;                                     // spheres + BVH (random_scene)
@@ -105,6 +105,9 @@ template <class T, uint32_t F> __device__ __host__ constexpr uint32_t sorted_lds
     return (12u + ((F & F_MOVING) ? 1u : 0u) + ((F & F_UV) ? 2u : 0u)) * RT_SORT_BLOCK * (uint32_t)sizeof(T) + 24u * RT_SORT_BLOCK + 384u * RT_SORT_TILE_H + 144u +
            lds_perlin_tables<T, F>() * (uint32_t)sizeof(DPerlin<T>);
 }
+#ifndef RT_SORTED_UV_WAVES
+#define RT_SORTED_UV_WAVES 3
+#endif
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_sorted() {
 #ifdef RT_SORTED_MAX_WAVES
     constexpr uint32_t most = RT_SORTED_MAX_WAVES;
@@ -119,7 +122,7 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
     // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
     // blocks per CU that LDS admits x waves per block / 4 SIMDs
     constexpr uint32_t by_lds = 163840u / sorted_lds_bytes<T, F>() * (RT_SORT_BLOCK / 64u) / 4u;
-    return (sizeof(T) == 8 && (F & F_UV)) ? 2 : (by_lds >= most ? (int)most : (int)(by_lds < 1u ? 1u : by_lds));
+    return (sizeof(T) == 8 && (F & F_UV)) ? (by_lds >= 3u ? RT_SORTED_UV_WAVES : (int)by_lds) : (by_lds >= most ? (int)most : (int)(by_lds < 1u ? 1u : by_lds));
 }
 }  // namespace rt
 

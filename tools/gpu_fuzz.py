@@ -3,7 +3,7 @@
 rebuilt from the same description — probe ids/t bit-exact, frames sample-for-sample.  Not part of the test suite
 (the suite runs seeds 0..11); run by hand:  python tools/gpu_fuzz.py FIRST LAST [generator]
 generator: a scene generator of tests/flat_fuzz.py (random_scene, tie_scene, medium_scene, texture_scene, extreme_scene, far_scene,
-pile_scene, odd_lights_scene); default random_scene."""
+pile_scene, odd_lights_scene, cross_tie_scene, instancing_scene); default random_scene."""
 import os
 import sys
 
