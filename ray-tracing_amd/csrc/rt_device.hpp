@@ -92,7 +92,41 @@ template <class T> struct alignas(16) DPerlin {
 };
 struct DImage { const uint8_t* rgb; uint32_t width, height; };
 template <class T> struct DXform { T v[3]; uint32_t kind; };
-template <class T> struct DInstance { T density; uint32_t geom_kind, geom_index, xform_begin, xform_count, is_medium, phase_material; };
+// `prim`: a COPY of prims[geom_index] where the geometry is one primitive (geom_kind 0; zeros for a tree).  The scans over the world
+// and the light list read an entry and its primitive with one address: as two records the primitive's address came out of the
+// instance's, a second scalar-load round trip per list entry of every cast.
+template <class T> struct alignas(16) DInstance { T density; uint32_t geom_kind, geom_index, xform_begin, xform_count, is_medium, phase_material; DPrim<T> prim; };
+// The whole record in one go (16-byte pieces, which the backend merges into the widest scalar loads): read field by field through a
+// reference, each field is loaded where it is first needed — behind the branch on the field before — and a list entry costs four to
+// five dependent scalar-load round trips instead of one.
+template <class T> __device__ inline DInstance<T> load_record(const DInstance<T>* p) {
+#if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__)
+    return *p;
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int N = (int)(sizeof(DInstance<T>) / 16);
+    static_assert(sizeof(DInstance<T>) % 16 == 0, "DInstance is read in 16-byte pieces");
+    union U { DInstance<T> r; u32x4 q[N]; __device__ U() {} } u;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int k = 0; k < N; k++) u.q[k] = src[k];
+    // every dword passes through readfirstlane — free for a value that sits in a scalar register, and a convergent operation, which
+    // the compiler may not make dependent on a branch: none of the loads can be moved below the test of another field
+    union W { u32x4 q[N]; int w[N * 4]; __device__ W() {} } x;
+#pragma unroll
+    for (int k = 0; k < N; k++) x.q[k] = u.q[k];
+#pragma unroll
+    for (int k = 0; k < N * 4; k++) x.w[k] = __builtin_amdgcn_readfirstlane(x.w[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) u.q[k] = x.q[k];
+    return u.r;
+#endif
+}
+// A list entry as the scan sees it: the copy read in one go, or (EAGER false) the record in memory, read field by field.  (The copy
+// must not be indexed with a run-time subscript: it would stop being registers.)
+template <bool EAGER, class T> struct RecordOf;
+template <class T> struct RecordOf<true, T> { DInstance<T> r; __device__ explicit RecordOf(const DInstance<T>* p) : r(load_record(p)) {} };
+template <class T> struct RecordOf<false, T> { const DInstance<T>& r; __device__ explicit RecordOf(const DInstance<T>* p) : r(*p) {} };
 // Threaded BVH: the reference's fixed left-then-right recursion (src/bvh.rs:114-129) needs no
 // stack when internal nodes AND leaves are laid out in pre-order and each internal node knows
 // where its subtree ends: box hit -> next entry, box miss -> skip.  prim >= 0 marks a leaf.
@@ -1021,11 +1055,18 @@ __device__ inline bool walk_fast(const DScene<T>& sc, Walk<T>& w, V3<T> o, V3<T>
     return !doubt;
 }
 
+// The primitive of a one-primitive list entry: the entry's own copy; the flat (u,v) variant reads the primitive table instead
+// (measured: with the copy it spills 80 instead of 48 B per lane, earth -1.2 %).
+template <class T, uint32_t F> __device__ inline const DPrim<T>& prim_of(const DScene<T>& sc, const DInstance<T>& in) {
+    if (has<F>(F_UV) && !has<F>(F_BVH)) return sc.prims[in.geom_index];
+    return in.prim;
+}
 // Geometry of an instance: one primitive, or a complete BVH walk.
 template <class T, uint32_t F>
-__device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_t geom_index, V3<T> o, V3<T> d, const RayInv<T>& inv, T time,
+__device__ inline bool geom_hit(const DScene<T>& sc, const DInstance<T>& in, V3<T> o, V3<T> d, const RayInv<T>& inv, T time,
                                 T t_min, T t_max, T& t_out, int& prim_out, int& side_out, bool& cross_tie, bool lead = false,
                                 T t_max_list = T(0)) {
+    const uint32_t geom_kind = in.geom_kind, geom_index = in.geom_index;
     // cross_tie (variants with trees, f64): set when a candidate distance equals t_max, the closest distance of the instances tested
     // before — the one case in which the ORDER of the world scan decides (world_hit)
     if (!has<F>(F_BVH) || geom_kind == 0) {
@@ -1034,10 +1075,10 @@ __device__ inline bool geom_hit(const DScene<T>& sc, uint32_t geom_kind, uint32_
         bool h;
         if (has<F>(F_BVH) && sizeof(T) == 8) {
             bool tie;
-            h = prim_hit_tie<T, F>(sc.prims[geom_index], o, d, inv, time, t_min, t_max, t_out, side_out, tie);
+            h = prim_hit_tie<T, F>(prim_of<T, F>(sc, in), o, d, inv, time, t_min, t_max, t_out, side_out, tie);
             cross_tie |= tie;
         } else {
-            h = prim_hit<T, F>(sc.prims[geom_index], o, d, inv, time, t_min, t_max, t_out, side_out);
+            h = prim_hit<T, F>(prim_of<T, F>(sc, in), o, d, inv, time, t_min, t_max, t_out, side_out);
         }
         RT_PCE(6);
         return h;
@@ -1237,7 +1278,15 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
     bool zone_order = n_zone != 0u && !wave_any(!(ray.time >= sc.fast_lo && ray.time <= sc.fast_hi)), zone_tie = false;
     for (uint32_t j = 0; j < sc.n_world; j++) {
         const uint32_t i = (has<F>(F_BVH) && zone_order && j < n_zone) ? sc.world_order[j] : j;
-        const DInstance<T>& in = sc.world[i];
+        #if defined(RT_LAZY_RECORDS)
+        const RecordOf<false, T> entry(sc.world + i);
+#else
+        // in one go where it measured faster (round 3, f64: cornell_box +2.1 %, two_perlin_spheres +0.4 %); the variants with media or
+        // (u,v) are short of registers and lost (cornell_smoke -1.8 %, earth -3.5 %: 32 more scalars live, 48 -> 80 B of spills), and
+        // with trees in the list the walks dominate
+        const RecordOf<!(has<F>(F_BVH) || has<F>(F_MEDIUM) || has<F>(F_UV)), T> entry(sc.world + i);
+#endif
+        const DInstance<T>& in = entry.r;
         V3<T> o = ray.ori, d = ray.dir;
         RT_PCB();
 #if defined(RT_SHARED_RECIP)
@@ -1277,7 +1326,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
         };
         if (has<F>(F_MEDIUM) && med && in.geom_kind == 0) {  // a single sphere or cuboid as boundary: both searches share their arithmetic
             T tb = T(0);
-            const int n = boundary_two<T, F>(sc.prims[in.geom_index], o, d, ray.time, ta, tb);
+            const int n = boundary_two<T, F>(prim_of<T, F>(sc, in), o, d, ray.time, ta, tb);
             if (n >= 0) {
                 if (n == 2) medium_event(tb);
                 RT_PCE(7);
@@ -1295,8 +1344,8 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
                 T t = Lim<T>::max(); int prim = -1, side = 0;
                 bool h;
                 bool unused = false;
-                if (has<F>(F_MEDIUM_BVH)) h = geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, lo, Lim<T>::max(), t, prim, side, unused);
-                else h = prim_hit<T, F>(sc.prims[in.geom_index], o, d, inv, ray.time, lo, Lim<T>::max(), t, side);
+                if (has<F>(F_MEDIUM_BVH)) h = geom_hit<T, F>(sc, in, o, d, inv, ray.time, lo, Lim<T>::max(), t, prim, side, unused);
+                else h = prim_hit<T, F>(prim_of<T, F>(sc, in), o, d, inv, ray.time, lo, Lim<T>::max(), t, side);
                 if (!h) break;
                 found++;
                 if (pass == 0) ta = t; else tb = t;
@@ -1309,7 +1358,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
             T t = closest; int prim = -1, side = 0;
             bool tie = false;
             const bool lead = has<F>(F_BVH) && zone_order && i == 0u;  // (list entry 0 met later than in the list: only as a tree of the zone)
-            if (geom_hit<T, F>(sc, in.geom_kind, in.geom_index, o, d, inv, ray.time, t_min, closest, t, prim, side, tie, lead, t_max)) {
+            if (geom_hit<T, F>(sc, in, o, d, inv, ray.time, t_min, closest, t, prim, side, tie, lead, t_max)) {
                 any = true; closest = t; hit.t = t; hit.inst = (int)i; hit.prim = prim; hit.side = side;
             }
             if (has<F>(F_BVH) && sizeof(T) == 8) zone_tie |= tie;

@@ -347,9 +347,11 @@ inline int32_t sah_build(std::vector<SahLeaf>& leaves, size_t lo, size_t hi, Sah
     return me;
 }
 
-template <class T> void convert_instances(const RtInstance* ins, uint32_t n, std::vector<DInstance<T>>& out) {
+template <class T> void convert_instances(const RtInstance* ins, uint32_t n, const std::vector<DPrim<T>>& prims, std::vector<DInstance<T>>& out) {
     for (uint32_t i = 0; i < n; i++) {
         DInstance<T> o;
+        std::memset(&o, 0, sizeof o);
+        if (ins[i].geom_kind == RT_GEOM_PRIM) o.prim = prims[ins[i].geom_index];  // (rt_device.hpp: DInstance)
         o.density = (T)ins[i].density;
         o.geom_kind = ins[i].geom_kind; o.geom_index = ins[i].geom_index;
         o.xform_begin = ins[i].xform_begin; o.xform_count = ins[i].xform_count;
@@ -465,8 +467,8 @@ template <class T> void pack_scene(const RtSceneDesc* d, PackedScene<T>& h) {
         o.kind = d->xforms[i].kind;
         h.xforms.push_back(o);
     }
-    convert_instances<T>(d->world, d->n_world, h.world);
-    convert_instances<T>(d->lights, d->n_lights, h.lights);
+    convert_instances<T>(d->world, d->n_world, h.prims, h.world);
+    convert_instances<T>(d->lights, d->n_lights, h.prims, h.lights);
     h.bvh_root_entry.assign(d->bvh.n_nodes, -1);
     auto add_roots = [&](const RtInstance* ins, uint32_t n) {
         for (uint32_t i = 0; i < n; i++)

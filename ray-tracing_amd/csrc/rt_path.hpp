@@ -26,7 +26,9 @@ __device__ inline T rect_pdf(int axis, T a1, T a2, T b1, T b2, T k, T face, V3<T
     return T(0);
 }
 
-template <class T, uint32_t F> __device__ inline T prim_pdf_value(const DPrim<T>& p, V3<T> o, V3<T> v) {
+// p: the primitive's fields (may be a copy held in registers); pm: the same primitive in memory, for the run-time subscripts of
+// the cuboid's side loop (a subscripted copy would stop being registers)
+template <class T, uint32_t F> __device__ inline T prim_pdf_value(const DPrim<T>& p, const DPrim<T>& pm, V3<T> o, V3<T> v) {
     const uint32_t kind = p.kind;
     if (has<F>(F_SPHERE) && kind == 0) {  // src/objects.rs:126-137
         T t;
@@ -51,7 +53,7 @@ template <class T, uint32_t F> __device__ inline T prim_pdf_value(const DPrim<T>
 #pragma nounroll
         for (int i = 0; i < 6; i++) {
             int axis; T a1, a2, b1, b2, k, face;
-            cuboid_side(p, i, axis, a1, a2, b1, b2, k, face);
+            cuboid_side(pm, i, axis, a1, a2, b1, b2, k, face);
             T term = weight * rect_pdf<T>(axis, a1, a2, b1, b2, k, face, o, v);
             ans = i == 0 ? term : ans + term;
         }
@@ -64,12 +66,17 @@ template <class T, uint32_t F> __device__ inline T lights_pdf_value(const DScene
     T weight = T(1) / (T)sc.n_lights;
     T ans = T(0);
     for (uint32_t i = 0; i < sc.n_lights; i++) {
-        const DInstance<T>& in = sc.lights[i];
+#if defined(RT_LAZY_RECORDS) || defined(RT_LAZY_LIGHTS)
+        const RecordOf<false, T> entry(sc.lights + i);
+#else
+        const RecordOf<!(has<F>(F_BVH) || has<F>(F_MEDIUM) || has<F>(F_UV)), T> entry(sc.lights + i);  // (as world_hit reads its list)
+#endif
+        const DInstance<T>& in = entry.r;
         T pv = T(0);
         if (!in.is_medium && in.geom_kind == 0) {  // ConstantMedium / BvhNode keep the default 0
             V3<T> o = origin, d = v;
             xform_ray<T, F>(sc, in, o, d);
-            pv = prim_pdf_value<T, F>(sc.prims[in.geom_index], o, d);
+            pv = prim_pdf_value<T, F>(in.prim, sc.lights[i].prim, o, d);
         }
         ans += weight * pv;
     }
@@ -121,7 +128,7 @@ __device__ inline void lambertian_sample(const DScene<T>& sc, const HitRecord<T>
             if (!in.is_medium && in.geom_kind == 0) {
                 V3<T> dummy(T(0), T(0), T(0));
                 xform_ray<T, F>(sc, in, o_l, dummy);
-                const DPrim<T>& p = sc.prims[in.geom_index];
+                const DPrim<T>& p = in.prim;
                 const uint32_t kind = p.kind;
                 if (has<F>(F_SPHERE) && kind == 0) {
                     mode = 1; q0 = p.d[0]; q1 = p.d[1]; q2 = p.d[2]; q3 = p.d[3];
