@@ -14,7 +14,7 @@ if wpc:
         t = l.split()
         tot += int(t[2])
         i = 3
-        while i < len(t):
+        while i + 2 < len(t):  # (a trailing `wall10ns <ticks>` pair is the wave's run time, not a phase)
             name = t[i]
             cyc[name] += int(t[i + 1]); lan[name] += int(t[i + 2])
             i += 3
