@@ -1530,6 +1530,52 @@ template <class T, class P> __device__ inline T perlin_turb(const P& pl, V3<T> p
     return rabs(accum);
 }
 
+// CheckerTexture (texture.rs:42-49) only asks whether sin(10x)·sin(10y)·sin(10z) < 0 — the SIGN of three sines, not their values.
+// sin_sign: the sign of sin(a) from one Cody–Waite step (fdlibm's __ieee754_rem_pio2 medium path: q = rint(|a|·2/π),
+// r = (|a| − q·pio2_1) − q·pio2_1t; q·pio2_1 is exact for q < 2^20) and the quadrant: sin|a| is sin r, cos r, −sin r, −cos r for
+// q mod 4 = 0..3, and cos r > 0 on |r| ≤ π/4.  The error of r is below 2·10^-20 + 2^-53·|r| for |a| < 2^20, so its sign is certain
+// wherever |r| > 10^-9; closer to a multiple of π, beyond 2^20, or for a NaN, `sure` is cleared and the caller evaluates the sines
+// themselves.  A correctly signed sine is what every libm returns (sin a = 0 only at a = 0: the product is then ±0, not negative),
+// so the decision is the reference's, not an approximation of it: ~12 instructions per axis instead of a ~90-instruction call
+// (tests/test_hostsim.py::test_checker_sign_decision_is_the_sine_product: 8·10^5 argument triples incl. neighbours of k·π).
+__device__ inline int sin_sign(double a, bool& sure) {
+    const double aa = ::fabs(a);
+    if (!(aa < 1048576.0)) { sure = false; return 0; }
+    if (aa == 0.0) return 0;
+    const double q = ::rint(aa * 6.36619772367581382433e-01);
+    const double r = (aa - q * 1.57079632673412561417e+00) - q * 6.07710050650619224932e-11;
+    const int qi = (int)q & 3;
+    int sgn;
+    if (qi & 1) sgn = qi == 1 ? 1 : -1;
+    else {
+        if (!(::fabs(r) > 1e-9)) sure = false;
+        sgn = (r > 0.0) == (qi == 0) ? 1 : -1;
+    }
+    return a < 0.0 ? -sgn : sgn;
+}
+__device__ inline bool checker_is_odd_body(double ax, double ay, double az) {
+    bool sure = true;
+    const int s = sin_sign(ax, sure) * sin_sign(ay, sure) * sin_sign(az, sure);
+    if (__builtin_expect(!sure, 0)) return rsin(ax) * rsin(ay) * rsin(az) < 0.0;
+    return s < 0;
+}
+#if !defined(RT_HOST_SIM) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) inline bool checker_is_odd_call(double ax, double ay, double az) { return checker_is_odd_body(ax, ay, az); }
+#else
+__device__ inline bool checker_is_odd_call(double ax, double ay, double az) { return checker_is_odd_body(ax, ay, az); }
+#endif
+// Inlined in the spheres + BVH variant (random_scene +2.5 %; as a call +1.2 %); a call elsewhere: in the generic variant the inlined
+// body cost 32 B of spills (final_scene, which has no checker at all, -3 %), in the flat sphere variant 16 B; f32 evaluates the sines.
+template <class T, uint32_t F> __device__ inline bool checker_is_odd(T ax, T ay, T az) {
+#ifndef RT_CHECKER_SINES
+    if constexpr (sizeof(T) == 8) {
+        if (!has<F>(F_BVH) || has<F>(F_MEDIUM) || has<F>(F_XFORM) || has<F>(F_LIGHTS) || has<F>(F_NOISE)) return checker_is_odd_call(ax, ay, az);
+        return checker_is_odd_body(ax, ay, az);
+    }
+#endif
+    return rsin(ax) * rsin(ay) * rsin(az) < T(0);
+}
+
 template <class T, uint32_t F> __device__ inline V3<T> texture_value(const DScene<T>& sc, uint32_t tex, T u, T v, V3<T> p) {
     if (!has<F>(F_TEXTURED)) return V3<T>(sc.textures[tex].color);  // texture.rs:16-18
     for (int guard = 0; guard < 16; guard++) {  // nested checkers: bounded descent instead of recursion
@@ -1537,8 +1583,7 @@ template <class T, uint32_t F> __device__ inline V3<T> texture_value(const DScen
         switch (t.kind) {
             case 0: return V3<T>(t.color);                                           // texture.rs:16-18
             case 1: {                                                                // texture.rs:42-49
-                T sines = rsin(T(10) * p.x) * rsin(T(10) * p.y) * rsin(T(10) * p.z);
-                tex = sines < T(0) ? t.odd : t.even;
+                tex = checker_is_odd<T, F>(T(10) * p.x, T(10) * p.y, T(10) * p.z) ? t.odd : t.even;
                 break;
             }
             case 2:                                                                  // texture.rs:27-33

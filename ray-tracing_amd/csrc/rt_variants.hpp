@@ -14,32 +14,18 @@ constexpr uint32_t V_NOISE = F_SPHERE | F_TEXTURED | F_NOISE;                   
 #endif
 constexpr uint32_t V_FINAL = RT_V_FINAL_MASK;  // final_scene: every feature but FrostedDielectric (only random_scene_light has one)
 
-// Register budget of the persistent render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and
-// SIMD: 2 -> 256, 3 -> 168, 4 -> 128), and the LDS budget of the staged BVH head (32-byte entries), sized so that
-// LDS admits as many blocks per CU as the register budget does.  All chosen from measurements (profiles/):
-//  * BVH walks are chains of dependent LDS fetches: they want resident waves more than they mind spills.
-//    spheres + BVH (random_scene): 4 waves with a 1024-entry head (32 KB + 6 KB tile sums per block) — f64 861 ->
-//    1173 Msamples/s against 2 waves / 2048 entries, f32 1232 -> 1414.  The generic variant (final_scene) stops at
-//    3 waves (f64 122 -> 144; at 4 its 128 registers spill it to half speed).
-//    With the two-way walk over the device's own trees (round 2) a node step is cheaper and the f64 spills weigh more:
-//    f64 3 waves 2026 against 1753 at 4 (and 1664 at 2); f32 stays at 4 (2970 against 2591 at 3).
-//    The generic f64 variant runs as fast at 2 waves as at 3 (final_scene 1024^2 @ 64 spp: 227 against 225 Msamples/s) with
-//    236 B of spills per lane instead of 576 B: at 3 waves the scratch of all resident waves (113 MB) does not fit the
-//    32 MB of L2 and 257 GB per launch went to HBM; at 2 waves it fits.  f32 kept 3 (370 against 272).
-//    LATER IN ROUND 2, once the uniform scene reads were scalar loads again (rt_kernels.inc: the job counter as a restrict
-//    parameter: 46 fewer live vector registers' worth of records), the balance tipped: 3 waves with 1184 LDS entries measure
-//    278 against 239 Msamples/s (f64, final_scene 1024^2 @ 64 spp; 314 against 255 at 2048^2) and f32 at 4 waves with 896 entries
-//    418 against 375 — issue slots busy 74 % instead of 58 %.  The price is the spill traffic again: 524 B per lane, 196 GB per
-//    launch through the memory side (810 GB/s, a tenth of the HBM peak; profiles/r02_final_*).  Throughput decides: 3 / 4 waves.
-//    -DRT_WAVES_PER_SIMD=2 -DRT_LDS_BVH_ENTRIES=2048 builds the low-traffic form (0.45 GB per launch).
-//    END OF ROUND 2 (scalar scene reads, streaming jobs, camera read at path start), measured again: spheres + BVH f64 at 4 waves is
-//    now 5-7 % FASTER than at 3 (random_scene 800x450 @ 100 spp 2281 -> 2388, @ 1600 spp 2505 -> 2689) — with 428 instead of 288 B
-//    of spills per lane, 112 MB of scratch resident and 11.7 GB instead of 0.65 GB per 15 ms launch through the memory side
-//    (profile of that build: issue slots busy 87 %, L2 hit 78 %).  Kept at 3: eighteen times the traffic for 5 % is the wrong
-//    trade for a kernel that shares the memory system with whatever else a node runs; -DRT_WAVES_PER_SIMD=4 builds the other form.
-//    The generic f64 variant stays at 3 either way (4 waves with an 864-entry head: 672 B of spills, -3 %).
-//  * no BVH: f64 3 waves (fits 168 without spilling, +23 % over 2), except the (u,v) / texture variants whose 168
-//    registers spill 272 B per lane (2 waves faster) and the noise variant (4 waves: +3 %); f32 4 waves.
+// Register budget of the persistent render kernel per instantiation, as waves per SIMD (512 VGPRs per lane and SIMD: 2 -> 256,
+// 3 -> 168, 4 -> 128), and the LDS budget of the staged node table (32-byte entries), sized so that LDS admits as many blocks per CU
+// as the register budget does.  All chosen from measurements; DESIGN.md §4 has the history (round 1: 4 waves for the three-way
+// walk; round 2: 3 waves, because at 4 the f64 variants spilled 430-670 B per lane and the scratch of the resident waves outgrew the
+// L2 — up to 257 GB per launch went to memory).  State after round 3, f64:
+//  * spheres + BVH (random_scene): 4 waves, 80 B of spills, 1024-entry table per 256-lane block; 0.97 GB per launch.
+//  * generic variant (final_scene): 4 waves, 112 B of spills (0 B at 3 waves, 9 % slower), 8.7 GB per launch, L2 hit 97 %; 864
+//    entries per 256-lane block, or one 1024-lane block per CU with 3945 (wave_block, below) when the trees need more.
+//  * no tree: flat (u,v) spheres (earth) 4 waves / 48 B; noise (two_perlin_spheres) 4 waves / 48 B; plain variants 3 waves / 0 B.
+//  What made 4 waves affordable: the large libm bodies (atan2 / asin, sincos, sin, log) are calls, not inlined code
+//  (rt_device.hpp), the media search has a branch of its own (F_MEDIUM_BVH), and radiance / counters are not carried per lane.
+//  f32: 4 waves everywhere.  -DRT_WAVES_PER_SIMD=n / -DRT_WPS_*=n / -DRT_LDS_BVH_ENTRIES=n build the other forms.
 template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd() {
 #ifdef RT_WAVES_PER_SIMD
     return RT_WAVES_PER_SIMD;
@@ -61,9 +47,9 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
 #endif
 }
 // Lanes per block of the persistent wave kernel.  Its waves never meet at a barrier after start-up, so a variant that stages a
-// BVH table in LDS can run as ONE block per CU (BIG: 256 lanes x waves per SIMD — 768 in f64, 1024 in f32): the CU then holds one
-// copy of the node table instead of one per 256-lane block, i.e. room for 3-4x the entries.  Round 3, same box, f64: final_scene
-// (2798 entries; 3 blocks per CU hold 1184 each: 42 % of the fetches from LDS, the rest from L2) 319.5 -> 334.7 Msamples/s at
+// BVH table in LDS can run as ONE block per CU (BIG: 256 lanes x waves per SIMD = 1024): the CU then holds one copy of the node
+// table instead of one per 256-lane block, i.e. room for four times the entries.  Round 3, same box, f64 (then at 3 waves): final_scene
+// (2798 entries; 3 blocks per CU held 1184 each: 42 % of the fetches from LDS, the rest from L2) 319.5 -> 334.7 Msamples/s at
 // 1024^2 @ 64 spp; random_scene, whose 959 entries fit either way, LOSES 1-4 % (a fixed ~0.1 ms per launch and ~1 %) — so the
 // launcher takes the big block only when the scene's trees do not fit the small block's table (rt_kernels.inc: launch_variant).
 template <class T, uint32_t F, bool BIG> __device__ __host__ constexpr uint32_t wave_block() {
@@ -82,7 +68,8 @@ template <class T, uint32_t F, bool BIG = false> __device__ __host__ constexpr u
 #endif
                 ) / 32u;
     }
-    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return RT_WPS_GENERIC == 4 ? 864u : 1184u;  // f64 generic: 3 blocks x (37 KB + 6.75 KB Perlin table + 6 KB)
+    // f64 generic: 4 blocks x (27 KB + 6.75 KB Perlin table + 6 KB of pixel sums), or 3 blocks x (37 KB + ...)
+    if (sizeof(T) == 8 && (F & F_BVH) && (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE))) return RT_WPS_GENERIC == 4 ? 864u : 1184u;
     return (sizeof(T) == 4 && (F & F_NOISE)) ? 896u : 1024u;  // f32 generic: 4 blocks x (28 KB + 4.75 KB Perlin table + 6 KB)
 #endif
 }
@@ -119,7 +106,8 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd_
     // 4 waves (0 at 3): 4 waves measure cornell_smoke 2484 -> 2754 Msamples/s @ 64 spp per launch, 2574 -> 2885 @ 1024.
     constexpr uint32_t most = sizeof(T) == 8 ? 4u : 7u;
 #endif
-    // f64 with (u,v) carried: 168 registers (3 waves) spill 280 B per lane and measured 7 % slower than 2 waves (earth)
+    // f64 with (u,v) carried: 2 waves in rounds 1-2 (168 registers spilled 280 B per lane, 7 % slower on earth); with the (u,v) and
+    // sincos bodies out of line (round 3) the sorted (u,v) variants need 168 registers and spill nothing: RT_SORTED_UV_WAVES = 3
     // blocks per CU that LDS admits x waves per block / 4 SIMDs
     constexpr uint32_t by_lds = 163840u / sorted_lds_bytes<T, F>() * (RT_SORT_BLOCK / 64u) / 4u;
     return (sizeof(T) == 8 && (F & F_UV)) ? (by_lds >= 3u ? RT_SORTED_UV_WAVES : (int)by_lds) : (by_lds >= most ? (int)most : (int)(by_lds < 1u ? 1u : by_lds));

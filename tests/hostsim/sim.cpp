@@ -4,6 +4,7 @@
 // compares the results with the oracle and the golden fixtures: T = double must agree bit for bit
 // (same arithmetic, same RNG, same libm).  What this does NOT cover is the HIP kernels' own
 // lane/wave logic (in-place regeneration, accumulation, stats): that is what the -m gpu tests do.
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,6 +103,17 @@ void* sim_scene_create(const RtSceneDesc* d, int* rc_out) {
     return s;
 }
 void sim_scene_destroy(void* s) { delete (SimScene*)s; }
+// rt_device.hpp: checker_is_odd (the sign-only decision) beside the product of the three sines it stands for, and whether it was sure
+void sim_checker(const double* xyz, uint32_t n, uint8_t* fast, uint8_t* plain, uint8_t* sure_out) {
+    for (uint32_t i = 0; i < n; i++) {
+        const double ax = xyz[3 * i], ay = xyz[3 * i + 1], az = xyz[3 * i + 2];
+        fast[i] = rt::checker_is_odd_body(ax, ay, az) ? 1 : 0;
+        plain[i] = (std::sin(ax) * std::sin(ay) * std::sin(az) < 0.0) ? 1 : 0;
+        bool sure = true;
+        (void)(rt::sin_sign(ax, sure) * rt::sin_sign(ay, sure) * rt::sin_sign(az, sure));
+        sure_out[i] = sure ? 1 : 0;
+    }
+}
 
 void sim_trace_primary(void* h, uint32_t W, uint32_t H, double time, double xi, uint32_t precision, int force_generic, int32_t* ids, double* ts) {
     SimScene* s = (SimScene*)h;

@@ -252,3 +252,32 @@ def test_sim_bvh_cull_is_invisible(sim, name):
         ids, ts = sc.primary(W, H, tm, 0.5)
         oi, ot = oc.trace_primary(W, H, tm, 0.5)
         assert np.array_equal(ids, oi) and np.array_equal(ts, ot)
+
+
+def test_checker_sign_decision_is_the_sine_product(sim):
+    # rt_device.hpp: checker_is_odd<double> decides CheckerTexture's branch (texture.rs:42-49) from the SIGNS of the three sines
+    # (one range-reduction step each; the sines themselves where that step is not conclusive).  Against the plain product of
+    # libm sines: uniform arguments, arguments next to multiples of pi (where the sign flips), zeros, huge and non-finite ones.
+    rng = np.random.default_rng(20260311)
+    n = 400_000
+    a = rng.uniform(-1.2e4, 1.2e4, size=(n, 3))
+    k = rng.integers(-300_000, 300_000, size=200_000).astype(np.float64)
+    near = k * np.pi
+    ulps = rng.integers(-3, 4, size=near.shape)
+    for _ in range(3):
+        near = np.where(ulps > 0, np.nextafter(near, np.inf), np.where(ulps < 0, np.nextafter(near, -np.inf), near))
+        ulps = ulps - np.sign(ulps)
+    b = rng.uniform(-50.0, 50.0, size=(near.size, 3))
+    b[:, 0] = near
+    b[::2, 1] = near[::-1][::2] * 0.5  # odd multiples of pi/2 as well
+    special = np.array([[0.0, 1.0, 1.0], [-0.0, 1.0, 1.0], [1.0, 0.0, -1.0], [1e300, 1.0, 1.0], [np.inf, 1.0, 1.0], [np.nan, 1.0, 1.0],
+                        [1048575.9, 1.0, -1.0], [1048576.0, -1.0, 1.0], [-1048577.0, 2.0, 4.0], [5e-324, -1.0, 1.0], [-5e-324, 1.0, 1.0],
+                        [4.0, 4.0, 4.0], [-4.0, 4.0, 4.0], [np.pi, np.pi, np.pi], [-np.pi, 1.0, 1.0], [2 * np.pi, 1.0, 1.0]])
+    xyz = np.ascontiguousarray(np.concatenate([a, b, special]))
+    m = xyz.shape[0]
+    fast, plain, sure = (np.zeros(m, np.uint8) for _ in range(3))
+    sim.sim_checker.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    sim.sim_checker(xyz.ctypes.data, m, fast.ctypes.data, plain.ctypes.data, sure.ctypes.data)
+    assert np.array_equal(fast, plain), xyz[fast != plain][:5]
+    assert sure[:n].mean() > 0.999999 and 0.2 < plain[:n].mean() < 0.8  # the quick route decides practically every ordinary argument
+    assert sure[n:n + near.size].mean() < 0.9                           # and declines next to the multiples of pi (both routes ran)
