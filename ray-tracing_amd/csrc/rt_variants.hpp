@@ -22,7 +22,7 @@ constexpr uint32_t V_FINAL = RT_V_FINAL_MASK;  // final_scene: every feature but
 //  * spheres + BVH (random_scene): 4 waves, 80 B of spills, 1024-entry table per 256-lane block; 0.97 GB per launch.
 //  * generic variant (final_scene): 4 waves, 112 B of spills (0 B at 3 waves, 9 % slower), 8.7 GB per launch, L2 hit 97 %; 864
 //    entries per 256-lane block, or one 1024-lane block per CU with 3945 (wave_block, below) when the trees need more.
-//  * no tree: flat (u,v) spheres (earth) 4 waves / 48 B; noise (two_perlin_spheres) 4 waves / 48 B; plain variants 3 waves / 0 B.
+//  * no tree: flat (u,v) spheres (earth) 4 waves / 48 B; noise (two_perlin_spheres) 4 waves / 48 B; plain variants 4 waves / 32 B.
 //  What made 4 waves affordable: the large libm bodies (atan2 / asin, sincos, sin, log) are calls, not inlined code
 //  (rt_device.hpp), the media search has a branch of its own (F_MEDIUM_BVH), and radiance / counters are not carried per lane.
 //  f32: 4 waves everywhere.  -DRT_WAVES_PER_SIMD=n / -DRT_WPS_*=n / -DRT_LDS_BVH_ENTRIES=n build the other forms.
@@ -43,7 +43,10 @@ template <class T, uint32_t F> __device__ __host__ constexpr int waves_per_simd(
         if (F & (F_MEDIUM | F_XFORM | F_LIGHTS | F_NOISE)) return sizeof(T) == 8 ? RT_WPS_GENERIC : 4;  // the generic variant (final_scene)
         return sizeof(T) == 8 ? RT_WPS_SPHERES_BVH : 4;                                     // spheres + BVH (random_scene)
     }
-    return sizeof(T) == 8 ? ((F & F_UV) ? RT_WPS_FLAT_UV : ((F & F_NOISE) ? 4 : 3)) : 4;
+#ifndef RT_WPS_PLAIN
+#define RT_WPS_PLAIN 4  // (the wave kernel of the Cornell variants — RT_RENDER_NO_SORT / _DETERMINISTIC: 140 registers at 3 waves, 32 B of spills at 4: +8 % / +6 %)
+#endif
+    return sizeof(T) == 8 ? ((F & F_UV) ? RT_WPS_FLAT_UV : ((F & F_NOISE) ? 4 : RT_WPS_PLAIN)) : 4;
 #endif
 }
 // Lanes per block of the persistent wave kernel.  Its waves never meet at a barrier after start-up, so a variant that stages a
