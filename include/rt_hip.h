@@ -49,7 +49,9 @@ enum RtStatus {
  * that range may differ from the reference in the last bit of a normal).  RT_F32 is a throughput mode outside
  * the parity bar: the tests hold it to >= 99.5 % identical ids and t within 5e-4 relative on the probe (f32
  * cancellation in the sphere quadratic at coordinates ~1000), and its images are an independent estimate at the
- * Monte-Carlo noise floor. */
+ * Monte-Carlo noise floor — for scenes within f32's reach: once coordinates exceed ~10^4 times the 0.001 ray offset
+ * (|x| >~ 8000, where one f32 ulp is that offset) bounces re-hit their own surface and the estimate is biased; every
+ * launch still ends and every sample is counted (tools/gpu_f32_sanity.py). */
 enum RtPrecision { RT_F32 = 0, RT_F64 = 1 };
 
 /* ---- primitives: src/objects.rs:81-85,146-153,217-225,271-279,325-333,381-392 ------------- */
