@@ -1559,19 +1559,15 @@ __device__ inline bool checker_is_odd_body(double ax, double ay, double az) {
     if (__builtin_expect(!sure, 0)) return rsin(ax) * rsin(ay) * rsin(az) < 0.0;
     return s < 0;
 }
-#if !defined(RT_HOST_SIM) && defined(__HIP_DEVICE_COMPILE__)
-__device__ __attribute__((noinline)) inline bool checker_is_odd_call(double ax, double ay, double az) { return checker_is_odd_body(ax, ay, az); }
-#else
-__device__ inline bool checker_is_odd_call(double ax, double ay, double az) { return checker_is_odd_body(ax, ay, az); }
-#endif
-// Inlined in the spheres + BVH variant (random_scene +2.5 %; as a call +1.2 %); a call elsewhere: in the generic variant the inlined
-// body cost 32 B of spills (final_scene, which has no checker at all, -3 %), in the flat sphere variant 16 B; f32 evaluates the sines.
+// Used (inlined) by the spheres + BVH variant: random_scene +2.5 %.  The other variants keep the three sine calls: inlined, the body
+// cost the generic variant 32 B of spills (final_scene, which has no checker at all, -3 %); as a call — a callee that calls in turn —
+// 16 B of frame: 128 instead of 112 B of scratch per lane, with which the resident waves' scratch (33.5 MB) no longer fits the 32 MB
+// of L2 and the memory-side traffic of a final_scene launch doubles (8.7 -> 18.6 GB); the flat sphere variant 48 -> 64 B for no
+// measured gain.  f32 evaluates the sines.
 template <class T, uint32_t F> __device__ inline bool checker_is_odd(T ax, T ay, T az) {
 #ifndef RT_CHECKER_SINES
-    if constexpr (sizeof(T) == 8) {
-        if (!has<F>(F_BVH) || has<F>(F_MEDIUM) || has<F>(F_XFORM) || has<F>(F_LIGHTS) || has<F>(F_NOISE)) return checker_is_odd_call(ax, ay, az);
+    if constexpr (sizeof(T) == 8 && has<F>(F_BVH) && !(has<F>(F_MEDIUM) || has<F>(F_XFORM) || has<F>(F_LIGHTS) || has<F>(F_NOISE)))
         return checker_is_odd_body(ax, ay, az);
-    }
 #endif
     return rsin(ax) * rsin(ay) * rsin(az) < T(0);
 }
