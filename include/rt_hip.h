@@ -208,7 +208,7 @@ typedef struct RtRenderParams {
  * gives the same bits on every run (and on every gfx950), and d_accum of a zeroed buffer is the reference's sum
  * rounded to f32.  Cost: the wave-level kernel without sample chunks, block regrouping or streaming jobs, and a wave
  * is as slow as the lane with the longest paths; measured on one MI355X, f64, share of the default throughput: earth
- * 0.83, cornell_box 1024^2 @ 1024 spp 0.65 (@ 128 spp 0.61), final_scene 0.37, random_scene 0.32.
+ * 0.83, cornell_box 1024^2 @ 1024 spp 0.69 (@ 128 spp 0.64), final_scene 0.39, random_scene 0.33.
  * Implies RT_RENDER_NO_SORT. */
 enum RtRenderFlags { RT_RENDER_NO_SORT = 1, RT_RENDER_DETERMINISTIC = 2 };
 
