@@ -99,6 +99,7 @@ template <class T> struct alignas(16) DInstance { T density; uint32_t geom_kind,
 // The whole record in one go (16-byte pieces, which the backend merges into the widest scalar loads): read field by field through a
 // reference, each field is loaded where it is first needed — behind the branch on the field before — and a list entry costs four to
 // five dependent scalar-load round trips instead of one.
+// `p` must be the same address in every lane of the wave (the list scans' loop counters are): readfirstlane hands all lanes lane 0's.
 template <class T> __device__ inline DInstance<T> load_record(const DInstance<T>* p) {
 #if defined(RT_HOST_SIM) || !defined(__HIP_DEVICE_COMPILE__)
     return *p;
@@ -1278,7 +1279,7 @@ __device__ inline bool world_hit(const DScene<T>& sc, const Ray<T>& ray, T t_min
     bool zone_order = n_zone != 0u && !wave_any(!(ray.time >= sc.fast_lo && ray.time <= sc.fast_hi)), zone_tie = false;
     for (uint32_t j = 0; j < sc.n_world; j++) {
         const uint32_t i = (has<F>(F_BVH) && zone_order && j < n_zone) ? sc.world_order[j] : j;
-        #if defined(RT_LAZY_RECORDS)
+#if defined(RT_LAZY_RECORDS)
         const RecordOf<false, T> entry(sc.world + i);
 #else
         // in one go where it measured faster (round 3, f64: cornell_box +2.1 %, two_perlin_spheres +0.4 %); the variants with media or
