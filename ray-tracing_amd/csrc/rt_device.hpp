@@ -1504,6 +1504,17 @@ template <class T, class P> __device__ inline T perlin_noise(const P& pl, V3<T> 
     const uint32_t hx[2] = {pl.px((uint32_t)i & 255u), pl.px((uint32_t)(i + 1) & 255u)};
     const uint32_t hy[2] = {pl.py((uint32_t)j & 255u), pl.py((uint32_t)(j + 1) & 255u)};
     const uint32_t hz[2] = {pl.pz((uint32_t)k & 255u), pl.pz((uint32_t)(k + 1) & 255u)};
+    // texture.rs:156-160 writes a corner's weight as `i·uu + (1 − i)·(1 − uu)` with i = 0 or 1.  For every finite uu that IS uu
+    // (i = 1: uu + 0·(1 − uu) = uu ± 0) or 1 − uu (i = 0: 0·uu + (1 − uu)), bit for bit — uu = u²(3 − 2u) ≥ +0, so no signed-zero case
+    // arises — and for a NaN both forms are NaN.  The compiler may not drop `0·x` or `+ 0` by itself (NaN, signed zeros): written
+    // out, 12 of a lookup's ~135 vector instructions go (two_perlin_spheres: seven lookups per shade).
+#ifdef RT_PERLIN_REFERENCE_WEIGHTS
+    const T wu[2] = {T(0) * uu + T(1) * (T(1) - uu), T(1) * uu + T(0) * (T(1) - uu)};
+    const T wv[2] = {T(0) * vv + T(1) * (T(1) - vv), T(1) * vv + T(0) * (T(1) - vv)};
+    const T wz[2] = {T(0) * ww + T(1) * (T(1) - ww), T(1) * ww + T(0) * (T(1) - ww)};
+#else
+    const T wu[2] = {T(1) - uu, uu}, wv[2] = {T(1) - vv, vv}, wz[2] = {T(1) - ww, ww};
+#endif
     T accum = T(0);
 #pragma unroll
     for (int di = 0; di < 2; di++)
@@ -1512,8 +1523,7 @@ template <class T, class P> __device__ inline T perlin_noise(const P& pl, V3<T> 
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
                 V3<T> c = pl.vec(hx[di] ^ hy[dj] ^ hz[dk]);
-                accum += (T(di) * uu + (T(1) - T(di)) * (T(1) - uu)) * (T(dj) * vv + (T(1) - T(dj)) * (T(1) - vv)) *
-                         (T(dk) * ww + (T(1) - T(dk)) * (T(1) - ww)) * dot(c, V3<T>(u - T(di), v - T(dj), w - T(dk)));
+                accum += wu[di] * wv[dj] * wz[dk] * dot(c, V3<T>(u - T(di), v - T(dj), w - T(dk)));
             }
     return accum;
 }
