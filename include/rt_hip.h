@@ -300,6 +300,10 @@ int rt_debug_divide(const double* d_n, const double* d_d, uint64_t count, double
 /* Test hook, no counterpart in the reference: the UNGUARDED shared-denominator quotient routine that unit(v) and v / s use
  * on the device (rt_device.hpp: RecipCore); d_flag[i] = 1 where |d[i]| lies outside [2^-400, 2^400). */
 int rt_debug_divide_fast(const double* d_n, const double* d_d, uint64_t count, double* d_out, uint32_t* d_flag, void* stream);
+/* Test hook, no counterpart in the reference: the float-to-integer conversions of the textures (Rust `as i32` / `as u32`: texture.rs:29-30,
+ * 82-89,143-145).  Per input x eight int32 in d_out[8*i..]: as_i32(x), as_u32(x), as_i32((float)x), as_u32((float)x) by the conversion
+ * the device code uses (the hardware's saturating instructions), then the same four by the form that spells Rust's rules out. */
+int rt_debug_convert(const double* d_x, uint64_t count, int32_t* d_out, void* stream);
 
 /* Small helpers so a host without another HIP binding can drive the library. */
 int rt_device_alloc(void** d_ptr, uint64_t bytes);

@@ -67,6 +67,7 @@ def hip():
             "rt_allreduce_stats": ([vp, vp, vp], C.c_int),
             "rt_debug_divide": ([vp, vp, u64, vp, vp, vp], C.c_int),
             "rt_debug_divide_fast": ([vp, vp, u64, vp, vp, vp], C.c_int),
+            "rt_debug_convert": ([vp, u64, vp, vp], C.c_int),
             "rt_device_alloc": ([C.POINTER(vp), u64], C.c_int),
             "rt_device_free": ([vp], C.c_int),
             "rt_device_zero": ([vp, u64, vp], C.c_int),

@@ -1453,11 +1453,27 @@ __device__ inline void finish_hit(const DScene<T>& sc, const Ray<T>& ray, const 
 // ------------------------------------------------------------------------------------------
 // textures: src/texture.rs
 // ------------------------------------------------------------------------------------------
-// Rust `as i32`: truncating, saturating, NaN -> 0
-__device__ inline int32_t as_i32(double x) { return x != x ? 0 : (x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)x)); }
-__device__ inline int32_t as_i32(float x) { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647 : (x <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)x)); }
-__device__ inline uint32_t as_u32(double x) { return x != x ? 0u : (x >= 4294967295.0 ? 4294967295u : (x <= 0.0 ? 0u : (uint32_t)x)); }
-__device__ inline uint32_t as_u32(float x) { return x != x ? 0u : (x >= 4294967296.0f ? 4294967295u : (x <= 0.0f ? 0u : (uint32_t)x)); }
+// Rust `as i32` / `as u32`: truncating, saturating, NaN -> 0 (negative -> 0 for u32).  That is, to the letter, what the hardware's
+// conversion instructions do (V_CVT_I32_F64 etc.: round toward zero, out-of-range values and infinities saturate, NaN gives 0), while a
+// C++ cast of an out-of-range value is undefined — so the portable form below spells the cases out, and the compiler turns each into
+// ~14 instructions with two exec-mask branches around the very instruction that needs none of them.  The device code issues the
+// instruction itself (a Perlin turbulence lookup converts 21 times: ~290 of its ~1250 instructions; round 3).
+// tests/test_gpu_divide.py::test_float_to_int_conversions_are_rusts checks both forms against each other on the device.
+__device__ inline int32_t as_i32_portable(double x) { return x != x ? 0 : (x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (-2147483647 - 1) : (int32_t)x)); }
+__device__ inline int32_t as_i32_portable(float x) { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647 : (x <= -2147483648.0f ? (-2147483647 - 1) : (int32_t)x)); }
+__device__ inline uint32_t as_u32_portable(double x) { return x != x ? 0u : (x >= 4294967295.0 ? 4294967295u : (x <= 0.0 ? 0u : (uint32_t)x)); }
+__device__ inline uint32_t as_u32_portable(float x) { return x != x ? 0u : (x >= 4294967296.0f ? 4294967295u : (x <= 0.0f ? 0u : (uint32_t)x)); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_HOST_SIM) && !defined(RT_PORTABLE_CONVERT)
+__device__ inline int32_t as_i32(double x) { int32_t r; asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ inline int32_t as_i32(float x) { int32_t r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ inline uint32_t as_u32(double x) { uint32_t r; asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ inline uint32_t as_u32(float x) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#else
+__device__ inline int32_t as_i32(double x) { return as_i32_portable(x); }
+__device__ inline int32_t as_i32(float x) { return as_i32_portable(x); }
+__device__ inline uint32_t as_u32(double x) { return as_u32_portable(x); }
+__device__ inline uint32_t as_u32(float x) { return as_u32_portable(x); }
+#endif
 
 // Where a Perlin table is read from: the scene's global record, or the render kernel's LDS copy.
 template <class T> struct PerlinGlobal {

@@ -353,6 +353,16 @@ int rt_debug_divide_fast(const double* d_n, const double* d_d, uint64_t count, d
     return RT_OK;
 }
 
+/* Test hook: per input x, eight int32: as_i32(x), as_u32(x), as_i32((float)x), as_u32((float)x) by the device code's conversion, then
+ * the same four by the spelled-out form (rt_device.hpp). */
+int rt_debug_convert(const double* d_x, uint64_t count, int32_t* d_out, void* stream) {
+    if (!d_x || !d_out) return fail(RT_ERR_INVALID, "NULL buffer");
+    if (count == 0) return RT_OK;
+    if (count > 0xffffffffull * 256ull) return fail(RT_ERR_INVALID, "count too large");
+    HIP_TRY(rt::launch_convert_check(d_x, count, d_out, (hipStream_t)stream));
+    return RT_OK;
+}
+
 int rt_resolve(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb, void* stream) {
     if (!d_accum || !d_rgb) return fail(RT_ERR_INVALID, "NULL buffer");
     if (width == 0 || height == 0 || spp == 0 || (uint64_t)width * height * 3 > 0xffffffffull) return fail(RT_ERR_INVALID, "bad width/height/spp");

@@ -17,6 +17,7 @@ template <class T> hipError_t launch_trace_primary(const DScene<T>& sc, uint32_t
                                                    double medium_xi, int32_t* d_ids, double* d_t, hipStream_t stream);
 template <class T> hipError_t launch_sample_pixel(const DScene<T>& sc, uint32_t features, const RenderArgs& a, uint32_t x, uint32_t y,
                                                   uint32_t n, double* d_out, hipStream_t stream);
+hipError_t launch_convert_check(const double* d_x, uint64_t count, int32_t* d_out, hipStream_t stream);
 hipError_t launch_divide_fast(const double* d_n, const double* d_d, uint64_t count, double* d_out, uint32_t* d_flag, hipStream_t stream);
 hipError_t launch_divide_check(const double* d_n, const double* d_d, uint64_t count, double* d_shared, double* d_plain, hipStream_t stream);
 hipError_t launch_resolve(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb, hipStream_t stream);

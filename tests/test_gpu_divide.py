@@ -125,3 +125,37 @@ def test_unguarded_shared_denominator_quotient(gpu):
             assert (np.abs(got[tiny]) < 2.0 ** -190).all() and (np.abs(want[tiny]) < 2.0 ** -190).all()
             checked += int(exact.sum())
     assert checked > 8_000_000
+
+
+def test_float_to_int_conversions_are_rusts(gpu):
+    # rt_device.hpp: as_i32 / as_u32 — Rust's `as i32` / `as u32` (texture.rs: CheckerTextureUV, ImageTexture, Perlin::noise) are
+    # truncating, saturating and send NaN to 0; the device code leaves all of that to the hardware's conversion instructions.
+    # Checked here: against the spelled-out form compiled for the device, and against those rules restated in numpy.
+    rs = np.random.RandomState(11)
+    parts = [rs.uniform(-3e9, 5e9, 1 << 20), rs.uniform(-70000, 70000, 1 << 20), rs.standard_normal(1 << 18) * 1e-3,
+             rs.standard_normal(1 << 18) * 1e30]
+    edge = [0.0, -0.0, 0.5, -0.5, 0.999999999, -0.999999999, 1.0, -1.0, 2147483646.5, 2147483647.0, 2147483647.5, 2147483648.0,
+            2147483649.0, -2147483647.5, -2147483648.0, -2147483648.5, -2147483649.0, 4294967294.5, 4294967295.0, 4294967295.5,
+            4294967296.0, 4294967297.0, 1e300, -1e300, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 16777216.0, 16777217.0, 255.999, 1023.9999999]
+    near = np.concatenate([np.array([2147483647.0, -2147483648.0, 4294967295.0, 4294967296.0, 0.0])[:, None] + np.linspace(-3, 3, 49)[None, :]]).ravel()
+    x = np.ascontiguousarray(np.concatenate(parts + [np.array(edge), near]), dtype=np.float64)
+    dx = torch.from_numpy(x).cuda()
+    out = torch.empty((x.size, 8), dtype=torch.int32, device="cuda:0")
+    rc = _ffi.hip().rt_debug_convert(C.c_void_p(dx.data_ptr()), x.size, C.c_void_p(out.data_ptr()), None)
+    assert rc == 0, _ffi.hip().rt_last_error()
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, :4], o[:, 4:]), x[(o[:, :4] != o[:, 4:]).any(axis=1)][:8]
+
+    def rust_i32(v):
+        t = np.trunc(np.nan_to_num(v.astype(np.float64), nan=0.0, posinf=3e9, neginf=-3e9))
+        return np.clip(t, -2147483648.0, 2147483647.0).astype(np.int64).astype(np.int32)
+
+    def rust_u32(v):
+        t = np.trunc(np.nan_to_num(v.astype(np.float64), nan=0.0, posinf=5e9, neginf=-1.0))
+        return np.clip(t, 0.0, 4294967295.0).astype(np.int64).astype(np.uint32).view(np.int32)
+
+    with np.errstate(over="ignore"):
+        xf = x.astype(np.float32)
+    assert np.array_equal(o[:, 0], rust_i32(x)) and np.array_equal(o[:, 1], rust_u32(x))
+    assert np.array_equal(o[:, 2], rust_i32(xf)) and np.array_equal(o[:, 3], rust_u32(xf))
