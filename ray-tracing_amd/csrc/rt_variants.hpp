@@ -19,10 +19,13 @@ constexpr uint32_t V_FINAL = RT_V_FINAL_MASK;  // final_scene: every feature but
 // as the register budget does.  All chosen from measurements; DESIGN.md §4 has the history (round 1: 4 waves for the three-way
 // walk; round 2: 3 waves, because at 4 the f64 variants spilled 430-670 B per lane and the scratch of the resident waves outgrew the
 // L2 — up to 257 GB per launch went to memory).  State after round 3, f64:
-//  * spheres + BVH (random_scene): 4 waves, 80 B of spills, 1024-entry table per 256-lane block; 0.97 GB per launch.
-//  * generic variant (final_scene): 4 waves, 112 B of spills (0 B at 3 waves, 9 % slower), 8.7 GB per launch, L2 hit 97 %; 864
-//    entries per 256-lane block, or one 1024-lane block per CU with 3945 (wave_block, below) when the trees need more.
-//  * no tree: flat (u,v) spheres (earth) 4 waves / 48 B; noise (two_perlin_spheres) 4 waves / 48 B; plain variants 4 waves / 32 B.
+//  * spheres + BVH (random_scene): 4 waves, 96 B of scratch per lane, 1024-entry table per 256-lane block; 1.04 GB per launch.
+//  * generic variant (final_scene): 4 waves, 112 B (0 B at 3 waves, 9 % slower), 7.1 GB per launch, L2 hit 97 % — and not a byte to
+//    spare: 4096 resident waves x 64 lanes x 112 B = 29.4 MB of the 32 MB of L2; at 128 B the traffic doubles (measured).  864
+//    entries per 256-lane block, or one 1024-lane block per CU with 3945 (wave_block, below) when the trees need more.  The
+//    catch-all with FrostedDielectric: 3 waves, 80 B (240 B at 4 waves, 5 % slower).
+//  * no tree: flat (u,v) spheres (earth) 4 waves / 16 B; noise (two_perlin_spheres) 4 waves / 32 B; plain variants 4 waves / 16-32 B.
+//  tests/test_kernel_budgets.py holds the built library to these figures.
 //  What made 4 waves affordable: the large libm bodies (atan2 / asin, sincos, sin, log) are calls, not inlined code
 //  (rt_device.hpp), the media search has a branch of its own (F_MEDIUM_BVH), and radiance / counters are not carried per lane.
 //  f32: 4 waves everywhere.  -DRT_WAVES_PER_SIMD=n / -DRT_WPS_*=n / -DRT_LDS_BVH_ENTRIES=n build the other forms.
